@@ -1,0 +1,152 @@
+"""Pin the CPU oracle against golden vectors produced by the reference itself.
+
+The fixtures under tests/golden/*.json were written by tests/golden/make_golden.py,
+which imports the reference (in the build container only) and records its outputs.
+Integer containment counts must match bit-exact; normalised depths within 1e-12.
+"""
+import numpy as np
+import pytest
+
+from conftest import (assert_depths_close, depths_of, frame_values, golden_names,
+                      load_golden)
+
+TOL = 1e-12
+
+
+def _targets(fx, labels):
+    tc = fx["call"].get("to_compute")
+    if tc is None:
+        return None
+    return [labels.index(t) for t in tc]
+
+
+@pytest.mark.parametrize("name", golden_names(kind="univariate") + golden_names(kind="pointcloud_linf"))
+def test_univariate_depths(oracle, name):
+    fx = load_golden(name)
+    X = frame_values(fx["input"])                      # (T, n): rows = timepoints
+    J, relax = fx["call"]["J"], fx["call"]["relax"]
+    tg = _targets(fx, fx["input"]["columns"])
+    got = oracle.univariate_depths(X, tg, J=J, relax=relax)
+    assert_depths_close(got, depths_of(fx), TOL)
+    # integer numerators bit-exact where the fixture carries them (J == 2)
+    if "counts" in fx and fx["count_residual"] < 1e-6:
+        if relax:
+            cnt = oracle.mbd_counts(X, tg, 2)[:, 0]
+        else:
+            cnt = oracle.bd_strict_counts(X, tg)
+        assert cnt.tolist() == fx["counts"]
+
+
+@pytest.mark.parametrize("name", [n for n in golden_names(kind="univariate")
+                                  if load_golden(n)["call"]["relax"]
+                                  and len(load_golden(n)["input"]["columns"]) <= 25])
+def test_closed_form_equals_literal_enumeration(oracle, name):
+    """C(v,k)-C(A,k)-C(B,k) closed form (with NaN weights) == literal subset enumeration."""
+    fx = load_golden(name)
+    X = frame_values(fx["input"])
+    J = max(fx["call"]["J"], 3)
+    if J >= X.shape[0]:
+        J = fx["call"]["J"]
+    a = oracle.mbd_counts(X, None, J)
+    b = oracle.band_enum(X, None, J, relax=True)
+    assert (a == b).all()
+
+
+@pytest.mark.parametrize("name", [n for n in golden_names(kind="univariate")
+                                  if not load_golden(n)["call"]["relax"]
+                                  and load_golden(n)["call"]["J"] == 2
+                                  and len(load_golden(n)["input"]["columns"]) <= 25])
+def test_strict_bitmask_equals_literal_enumeration(oracle, name):
+    fx = load_golden(name)
+    X = frame_values(fx["input"])
+    a = oracle.bd_strict_counts(X, None)
+    b = oracle.band_enum(X, None, 2, relax=False)[:, 0]
+    assert (a == b).all()
+
+
+def test_both_layouts_agree(oracle):
+    rng = np.random.default_rng(5)
+    X = rng.integers(0, 6, size=(19, 13)).astype(float)
+    XF = np.asfortranarray(X)
+    assert (oracle.mbd_counts(X, None, 3) == oracle.mbd_counts(XF, None, 3)).all()
+    assert (oracle.bd_strict_counts(X) == oracle.bd_strict_counts(XF)).all()
+    assert (oracle.above_below(X) == oracle.above_below(XF)).all()
+
+
+def test_numpy_restatement_agrees(oracle):
+    """Second, independently written restatement (oracle_np) on a tie-heavy case."""
+    from oracle import oracle_np
+    rng = np.random.default_rng(8)
+    X = rng.integers(0, 4, size=(7, 8)).astype(float)
+    X[2, 3] = np.nan
+    for relax in (True, False):
+        for J in (2, 3):
+            want = [oracle_np.univariate_band_depth(X, i, J, relax) for i in range(X.shape[1])]
+            got = oracle.univariate_depths(X, None, J=J, relax=relax)
+            assert_depths_close(got, want, TOL)
+
+
+@pytest.mark.parametrize("name", golden_names(kind="multivariate"))
+def test_multivariate_simplex(oracle, name):
+    fx = load_golden(name)
+    P = np.stack([frame_values(f) for f in fx["input"]])        # (n, T, d)
+    relax = fx["call"]["relax"]
+    tg = fx["call"].get("to_compute")
+    got = oracle.multivariate_depths(P, tg, relax=relax)
+    assert_depths_close(got, depths_of(fx), TOL)
+    assert fx["count_residual"] < 1e-6
+    assert oracle.multi_simplex_counts(P, tg, relax).tolist() == fx["counts"]
+
+
+@pytest.mark.parametrize("name", golden_names(kind="pointcloud"))
+def test_pointcloud(oracle, name):
+    fx = load_golden(name)
+    P = frame_values(fx["input"])
+    tg = _targets(fx, fx["input"]["index"])
+    if fx["call"]["containment"] == "simplex":
+        got = oracle.pointcloud_depths(P, tg)
+        assert_depths_close(got, depths_of(fx), TOL)
+        assert oracle.pointcloud_simplex_counts(P, tg).tolist() == fx["counts"]
+    else:
+        got = oracle.l1_depth(P, tg)
+        assert_depths_close(got, depths_of(fx), TOL)
+
+
+def test_hull_restatement_vs_lp_call(oracle):
+    """Geometric restatement == the reference's third-party LP call on random and degenerate sets."""
+    from oracle import oracle_np
+    rng = np.random.default_rng(17)
+    n_checked = 0
+    for d in (1, 2, 3, 4):
+        for _ in range(40):
+            P = rng.normal(size=(d + 1, d))
+            x = rng.normal(size=d) * 0.4
+            assert oracle.point_in_hull(P, x) == oracle_np.is_in_simplex_lp(P, x)
+            n_checked += 1
+    # degenerate: all points on one ray (the reference's own multivariate generator shape)
+    for _ in range(40):
+        base = rng.random(3)
+        r = rng.random(4)
+        P = np.outer(r, base)
+        x = rng.random() * base
+        assert oracle.point_in_hull(P, x) == oracle_np.is_in_simplex_lp(P, x)
+    # boundary: lattice points on edges / vertices are contained (closed simplex)
+    tri = np.array([[0.0, 0.0], [2.0, 0.0], [0.0, 2.0]])
+    for x in ([1.0, 0.0], [1.0, 1.0], [0.0, 0.0], [2.0, 0.0], [0.5, 0.5]):
+        assert oracle.point_in_hull(tri, np.array(x)) is True
+        assert oracle_np.is_in_simplex_lp(tri, x) is True
+    for x in ([1.0, 1.0 + 1e-5], [-1e-5, 0.5], [2.1, 0.0]):
+        assert oracle.point_in_hull(tri, np.array(x)) is False
+        assert oracle_np.is_in_simplex_lp(tri, x) is False
+
+
+def test_l1_matches_numpy_restatement(oracle):
+    from oracle import oracle_np
+    rng = np.random.default_rng(3)
+    P = rng.normal(size=(17, 4))
+    want = [oracle_np.l1_depth(P, i) for i in range(17)]
+    assert_depths_close(oracle.l1_depth(P), want, TOL)
+    # coincident points give NaN in the reference (0/0, _pointcloud.py:146)
+    P[5] = P[2]
+    got = oracle.l1_depth(P)
+    assert np.isnan(got[5]) and np.isnan(got[2]) and np.isnan(got).sum() == 2
