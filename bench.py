@@ -1,0 +1,151 @@
+#!/usr/bin/env python3
+"""bench.py -- curve-pairs/s of modified band depth (J=2) on MI355X.
+
+Workload (BASELINE.json configs[1] at N=1): every rank owns n_loc = 10 000 synthetic
+random-walk curves x T = 1 000 timepoints (fp64, time-major); the data set is the
+union of all ranks' curves (n = N * n_loc), each rank computes the exact MBD
+containment totals of its own curves against the full set.  One step = one pass of
+the hot path: (N > 1: RCCL all-gather of the curve blocks) + sd_mbd_counts on the
+resident matrix.  value = ordered (target, other) curve pairs evaluated over all T
+timepoints per second, whole job.
+
+Prints ONE JSON line (rank 0).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK = 8.0e12          # B/s, MI355X spec (MI355X_MICROARCH.md)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--n-loc", type=int, default=10000)
+    ap.add_argument("--T", type=int, default=1000)
+    ap.add_argument("--J", type=int, default=2)
+    ap.add_argument("--algo", default="auto", choices=["auto", "pairwise", "rank"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-targets", type=int, default=4096)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from statdepth_amd import _native, engine
+    from statdepth_amd._native import ALGOS, check
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    N = world
+    assert args.gpus == N, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    lib = _native.require_device()
+
+    T, n_loc, J = args.T, args.n_loc, args.J
+    n = n_loc * N
+    # synthetic curves: random walks (SURVEY.md 8(d) config 2 recipe), one block per rank
+    rng = np.random.default_rng(1234 + rank)
+    X_host = rng.normal(size=(T, n_loc)).cumsum(axis=0)
+    X_loc = torch.from_numpy(X_host).to(dev)                       # [T, n_loc] time-major, resident in HBM
+    if N > 1:
+        gathered = torch.empty((N, T, n_loc), dtype=torch.float64, device=dev)
+        X_all = torch.empty((T, n), dtype=torch.float64, device=dev)
+    else:
+        X_all = X_loc
+    targets = torch.arange(rank * n_loc, (rank + 1) * n_loc, dtype=torch.int64, device=dev)
+    out = torch.empty((n_loc, J - 1), dtype=torch.int64, device=dev)
+    algo = ALGOS[args.algo]
+    wsb = lib.sd_mbd_workspace_bytes(T, n, n, 1, n_loc, J, algo)
+    ws = torch.empty(int(wsb), dtype=torch.uint8, device=dev)
+    stream = torch.cuda.current_stream(dev)
+
+    def step():
+        if N > 1:
+            # exchange step: ring all-gather of curve blocks over xGMI, then lay rows out contiguously
+            dist.all_gather_into_tensor(gathered, X_loc)
+            X_all.view(T, N, n_loc).copy_(gathered.permute(1, 0, 2))
+        check(lib.sd_mbd_counts(X_all.data_ptr(), T, n, n, 1, targets.data_ptr(), n_loc, J, algo,
+                                out.data_ptr(), ws.data_ptr(), wsb, stream.cuda_stream))
+
+    def barrier():
+        if N > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record(stream)
+    for _ in range(args.steps):
+        step()
+    ev1.record(stream)
+    barrier()
+    dt = time.perf_counter() - t0
+    dev_ms = ev0.elapsed_time(ev1) / args.steps          # device time per step on the launch stream
+    if N > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    ms_per_step = dt / args.steps * 1e3
+    pairs_per_step = float(n_loc) * N * (n - 1)          # ordered (target, other) pairs, whole job
+    value = pairs_per_step / (dt / args.steps)
+
+    result_sum = int(out.sum().item())
+    if rank == 0:
+        used = "rank" if (args.algo == "rank" or (args.algo == "auto" and n <= 16384 and J <= 3)) else "pairwise"
+        bytes_alg = 8.0 * T * (n + n_loc) + 8.0 * n_loc * (J - 1)   # per GPU per call
+        achieved = bytes_alg / (dev_ms * 1e-3)
+        line = {
+            "metric": "curve-pairs/sec (MBD)", "value": value, "unit": "curve-pairs/s",
+            "n_gpus": N, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"MBD J={J}: {n} curves x {T} timepoints (n_loc={n_loc} targets per GPU), fp64 "
+                                   f"random walks, time-major", "algorithm": used,
+                       "parallelism": f"targets sharded x{N}" + (", RCCL all-gather of curve blocks" if N > 1 else "")},
+            "pair_timepoints_per_s": value * T,
+            "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK, "traffic": None,
+                         "kernel": "mbd_rank_kernel" if used == "rank" else "mbd_pairwise_kernel",
+                         "kernel_ms": dev_ms, "algorithmic_bytes": bytes_alg},
+            "checksum": result_sum,
+        }
+        if not args.no_cpu_baseline and N == 1:
+            import oracle
+            oracle.build()
+            m_cpu = min(args.cpu_targets, n_loc)
+            tg = np.arange(m_cpu, dtype=np.int64)
+            t1 = time.perf_counter()
+            want = oracle.mbd_counts(X_host, tg, J)
+            cpu_dt = time.perf_counter() - t1
+            got = out[:m_cpu].cpu().numpy()
+            assert (got == want).all(), "HIP counts differ from the CPU oracle on the baseline sample"
+            line["cpu_baseline"] = {
+                "value": m_cpu * (n - 1) / cpu_dt, "unit": "curve-pairs/s", "cores": oracle.num_threads(),
+                "kind": "port",
+                "sample": f"oracle_mbd_counts (C, OpenMP) on the first {m_cpu} of {n_loc} targets x all {n} curves x "
+                          f"{T} timepoints, {cpu_dt:.2f} s; work is linear in #targets",
+            }
+        print(json.dumps(line), flush=True)
+    if N > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

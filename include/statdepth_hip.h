@@ -1,0 +1,167 @@
+/*
+ * statdepth_hip.h -- C ABI of the MI355X (gfx950) band-depth engine.
+ *
+ * This is the drop-in boundary for statdepth's calculation layer
+ * (the files under statdepth/depth/calculations/ in the reference).  The reference has no
+ * FFI of its own -- its hot path is Python loops -- so each entry point below
+ * names the reference function whose inner loops it replaces; the host side
+ * (statdepth_amd/, Python) keeps the reference's FunctionalDepth /
+ * PointcloudDepth signatures and calls these through ctypes.  INTEGRATION.md
+ * shows the stub a statdepth maintainer would add to bind them.
+ *
+ * Conventions
+ *  - plain C types only; every data pointer is a DEVICE pointer (HBM) unless
+ *    the name says host; `stream` is a hipStream_t passed as void* (NULL = the
+ *    null stream).  Calls enqueue work and return; they do not synchronise.
+ *  - a univariate data set of n curves observed at T timepoints is addressed
+ *    as x(t,i) = X[t*st + i*sn] (strides in elements), so both pandas layouts
+ *    are accepted in place: C-contiguous T x n ("time-major", st=n, sn=1) and
+ *    F-contiguous ("curve-major", st=1, sn=T).  Kernels run time-major; a
+ *    curve-major input is transposed on the device into the workspace first.
+ *  - `targets` is an int64 device array of m curve / point indices (the
+ *    reference's `to_compute`), or NULL for "all, in order" (then m must be n).
+ *  - integer outputs are the tested contract (bit-exact vs the reference);
+ *    the fp64 normalisers (/T, /C(n,j) ...) stay on the host.
+ *  - every function returns SD_OK (0) or an error code; sd_last_error() gives
+ *    the message for the calling thread.
+ */
+#ifndef STATDEPTH_HIP_H
+#define STATDEPTH_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SD_ABI_VERSION 1
+
+enum sd_status {
+    SD_OK = 0,
+    SD_ERR_INVALID = 1,     /* bad argument (shape, stride, J, null pointer ...) */
+    SD_ERR_HIP = 2,         /* a HIP runtime call failed */
+    SD_ERR_NO_DEVICE = 3,   /* no gfx950 device visible */
+    SD_ERR_UNSUPPORTED = 4, /* valid request outside what the kernels cover */
+    SD_ERR_OVERFLOW = 5,    /* an int64 total could overflow (T*C(n-1,J) >= 2^63) */
+    SD_ERR_WORKSPACE = 6    /* workspace too small */
+};
+
+/* algorithm selector of sd_mbd_counts */
+enum sd_mbd_algo {
+    SD_MBD_AUTO = 0,
+    SD_MBD_PAIRWISE = 1, /* O(m n T): stream every curve against every target, compare + count */
+    SD_MBD_RANK = 2      /* O(n T log n): per-timepoint sort in LDS, ranks give the same integers */
+};
+
+/* ---- library / device ---------------------------------------------------- */
+int sd_abi_version(void);
+const char *sd_last_error(void);
+int sd_device_count(void);
+/* name (e.g. "gfx950...") and CU count of device `dev`; name buffer >= 64 bytes */
+int sd_device_info(int dev, char *name, int name_len, int *cu_count, size_t *hbm_bytes);
+int sd_set_device(int dev);
+
+/* ---- memory / stream helpers for clients without their own allocator ------ */
+int sd_malloc(void **dptr, size_t bytes);
+int sd_free(void *dptr);
+int sd_memcpy_h2d(void *dst, const void *src_host, size_t bytes, void *stream);
+int sd_memcpy_d2h(void *dst_host, const void *src, size_t bytes, void *stream);
+int sd_memset(void *dst, int value, size_t bytes, void *stream);
+int sd_stream_synchronize(void *stream);
+
+/* ---- K1+K2: modified band depth totals (relax=True) ------------------------
+ * Replaces: the subset loop of _univariate_band_depth (_functional.py:238-253)
+ * with _r2_containment(relax=True) (_containment.py:45-80) inside it, for all
+ * targets of _functionaldepth's loop (_functional.py:74-75).
+ *
+ * out[q*(J-1) + (j-2)] = sum over t of #{j-subsets of the OTHER n-1 curves whose
+ * band [min,max] (pandas skipna, inclusive ends) contains target q at t},
+ * j = 2..J.  The host forms S_nj = out/T and depth = sum_j S_nj / C(n,j).
+ * Computed from per-timepoint counts A (others strictly above), B (strictly
+ * below), N (NaN others), v = n-1-N:
+ *     sum_{k=1..j} C(N,j-k) * [C(v,k) - C(A,k) - C(B,k)]       (0 if x is NaN)
+ * which equals the reference's enumeration exactly (tests/test_oracle_golden.py).
+ * J in [2, 8]; SD_ERR_OVERFLOW if T*C(n-1,J) >= 2^63.
+ * `ws`/`ws_bytes`: device scratch of at least sd_mbd_workspace_bytes(...).
+ */
+size_t sd_mbd_workspace_bytes(int64_t T, int64_t n, int64_t st, int64_t sn, int64_t m, int J, int algo);
+int sd_mbd_counts(const double *X, int64_t T, int64_t n, int64_t st, int64_t sn,
+                  const int64_t *targets, int64_t m, int J, int algo,
+                  int64_t *out, void *ws, size_t ws_bytes, void *stream);
+
+/* Finest-granularity form of K1 (tests, diagnostics): AB[(q*T + t)*2 + {0,1}] =
+ * (#curves strictly above, #strictly below) target q at t, as uint32. */
+int sd_above_below(const double *X, int64_t T, int64_t n, int64_t st, int64_t sn,
+                   const int64_t *targets, int64_t m, uint32_t *AB,
+                   void *ws, size_t ws_bytes, void *stream);
+
+/* ---- K3: strict band depth (relax=False), J = 2 ------------------------------
+ * Replaces: the same loop (_functional.py:246-251) with `containment // len(curve)`
+ * (_containment.py:80): a pair counts only if its band contains the target at
+ * EVERY timepoint.  out[q] = number of such unordered pairs of other curves.
+ * depth = out / C(n,2) on the host.
+ */
+size_t sd_bd_strict_workspace_bytes(int64_t T, int64_t n, int64_t st, int64_t sn, int64_t m);
+int sd_bd_strict_counts(const double *X, int64_t T, int64_t n, int64_t st, int64_t sn,
+                        const int64_t *targets, int64_t m,
+                        int64_t *out, void *ws, size_t ws_bytes, void *stream);
+
+/* ---- K3b: strict band depth, general J (subset enumeration over bit masks) ----
+ * out[q*(J-1)+(j-2)] = #{j-subsets of others containing target q at every t}.
+ * J in [2, 4]; work grows as C(n-1,J) per target.
+ */
+size_t sd_bd_strict_j_workspace_bytes(int64_t T, int64_t n, int64_t st, int64_t sn, int64_t m, int J);
+int sd_bd_strict_j_counts(const double *X, int64_t T, int64_t n, int64_t st, int64_t sn,
+                          const int64_t *targets, int64_t m, int J,
+                          int64_t *out, void *ws, size_t ws_bytes, void *stream);
+
+/* ---- K5: L1 (spatial) depth of a point cloud ----------------------------------
+ * Replaces: _L1_depth (_pointcloud.py:125-150).  P is n x d row-major (rows =
+ * points).  out[q] = 1 - || sum_{y != x} (y-x)/||x-y|| || / n  (fp64; coincident
+ * points give NaN like the reference's 0/0).
+ */
+int sd_l1_depth(const double *P, int64_t n, int d, const int64_t *targets, int64_t m,
+                double *out, void *stream);
+
+/* ---- K4: simplex containment counts ---------------------------------------------
+ * Replaces: _is_in_simplex (_containment.py:138-176, an LP feasibility test
+ * through scipy.optimize.linprog) inside
+ *   - _pointwisedepth's subset loop (_pointcloud.py:50-54): sd_pointcloud_simplex_counts,
+ *     P n x d row-major, out[q] = #{(d+1)-subsets of the other n-1 points whose
+ *     simplex contains point q}; depth = out / C(n,d+1) on the host;
+ *   - _simplex_depth / _simplex_containment (_functional.py:281-285,
+ *     _containment.py:130-136): sd_multi_simplex_counts, P n x T x d row-major
+ *     (curve, timepoint, feature); per target and (d+1)-subset of the other
+ *     curves c = #{t: x_q(t) in simplex}; out[q] = sum c (relax != 0) or
+ *     sum [c == T] (relax == 0); depth = out / (T or 1) / C(n-1,d+1) on the host.
+ * Containment = the closed simplex (degenerate point sets allowed) with
+ * feasibility tolerance `tol` on the barycentric coordinates (1e-7 mirrors the
+ * LP solver's default).  d in [1, 8].
+ * subset enumeration is exhaustive: C(n-1,d+1) per target must be < 2^62.
+ */
+int sd_pointcloud_simplex_counts(const double *P, int64_t n, int d,
+                                 const int64_t *targets, int64_t m, double tol,
+                                 int64_t *out, void *stream);
+int sd_multi_simplex_counts(const double *P, int64_t n, int64_t T, int d,
+                            const int64_t *targets, int64_t m, int relax, double tol,
+                            int64_t *out, void *stream);
+
+/* Seeded uniform subset-sampling estimators for sizes where exhaustive
+ * enumeration is impossible (BASELINE.json configs 4 and 5; not in the
+ * reference).  For each target, `samples` (d+1)-subsets of the
+ * other items are drawn with a counter-based generator keyed by
+ * (seed, target index, sample number); out[q] = number of containing simplices
+ * (pointcloud) or sum over samples of c / [c == T] (multi).
+ */
+int sd_pointcloud_simplex_sampled(const double *P, int64_t n, int d,
+                                  const int64_t *targets, int64_t m, double tol,
+                                  int64_t samples, uint64_t seed, int64_t *out, void *stream);
+int sd_multi_simplex_sampled(const double *P, int64_t n, int64_t T, int d,
+                             const int64_t *targets, int64_t m, int relax, double tol,
+                             int64_t samples, uint64_t seed, int64_t *out, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* STATDEPTH_HIP_H */

@@ -1,0 +1,269 @@
+// mbd_rank.hip -- K1+K2, rank formulation: the same integers as the pairwise kernel in
+// O(n T log n).
+//
+// For one timepoint the counts A (others strictly above) and B (strictly below) of
+// every curve follow from its position in the sorted row: B = lower_bound(x),
+// A = n_valid - upper_bound(x).  One workgroup sorts a whole row X[t, 0:n] in LDS
+// (n <= 16384: 128 KiB of fp64 keys inside the CU's 160 KiB), every thread then
+// looks its own curves up by binary search and folds C(v,j) - C(A,j) - C(B,j) into
+// per-curve register accumulators that persist across the timepoints the workgroup
+// owns.  The matrix is read from HBM exactly once (coalesced rows), so this is the
+// formulation whose floor is the HBM roofline; what it actually pays for is the
+// LDS/VALU cost of the sort (DESIGN.md has the budget).
+//
+// Sort: bitonic network on fp64 keys only (no payload), v_min_f64 / v_max_f64 as the
+// compare-exchange.  Each thread keeps E keys in VGPRs; a level whose partner
+// distance lies inside the thread's register window is pure VALU, and the window is
+// moved by transposing through LDS ("layout b": register index = position bits
+// [b, b+log2 E)).  Windows with b <= 6 keep every wave inside its own 64*E-key block,
+// so those transposes need no workgroup barrier; only the four last stages cross
+// waves (8 barriers per row).  Descending sub-sequences are stored negated (sign-bit
+// flip at stage boundaries), so every compare-exchange is ascending and costs exactly
+// two fp64 instructions.  NaN keys are replaced by +inf and counted (pandas skipna,
+// _containment.py:68-69); padding up to the power of two is +inf as well.
+//
+// Replaces the same reference loops as mbd_pairwise.hip (_functional.py:246-251,
+// _containment.py:75-77); results are bit-identical to it and to the oracle.
+#include "sd_common.h"
+
+namespace sd {
+
+constexpr int RK_MAXG = 1024;   // max persistent workgroups (partial-sum rows)
+
+template <int NT, int E>
+struct RankCfg {
+    static constexpr int N = NT * E;
+    static constexpr int LE = (E == 1) ? 0 : (E == 2) ? 1 : (E == 4) ? 2 : (E == 8) ? 3 : 4;
+    static constexpr int LT = (NT == 256) ? 8 : (NT == 512) ? 9 : 10;
+    static constexpr int LN = LE + LT;
+    static constexpr int SLOTS = N + (N >> LE);       // padded: one slot per E keys
+    static constexpr size_t LDS_BYTES = (size_t)SLOTS * 8;
+};
+
+template <int LE>
+__device__ __forceinline__ int phys(int p) { return p + (p >> LE); }
+
+// position of (thread t, register r) when registers hold position bits [B, B+LE)
+template <int B, int LE>
+__device__ __forceinline__ int pos_of(int t, int r) {
+    return ((t >> B) << (B + LE)) | (r << B) | (t & ((1 << B) - 1));
+}
+
+__device__ __forceinline__ void cmpx(double &a, double &b) {
+    double lo = __builtin_fmin(a, b);
+    double hi = __builtin_fmax(a, b);
+    a = lo;
+    b = hi;
+}
+
+__device__ __forceinline__ double flip_sign(double v, unsigned m) {   // m = 0 or 0x80000000
+    unsigned long long u = __double_as_longlong(v);
+    u ^= ((unsigned long long)m) << 32;
+    return __longlong_as_double(u);
+}
+
+template <int NT, int E>
+struct RankSorter {
+    using C = RankCfg<NT, E>;
+    static constexpr int LE = C::LE;
+    static constexpr int LN = C::LN;
+
+    // window k of stage S: register bits start at wb(S,k)
+    static constexpr int wb(int S, int k) { return (S - (k + 1) * LE) > 0 ? (S - (k + 1) * LE) : 0; }
+
+    template <int BF, int BT>
+    static __device__ __forceinline__ void transpose(double (&k)[E], double *S, int t) {
+        constexpr bool global = (BF > 6) || (BT > 6);
+#pragma unroll
+        for (int r = 0; r < E; ++r) S[phys<LE>(pos_of<BF, LE>(t, r))] = k[r];
+        if constexpr (global) {
+            __syncthreads();
+        } else {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+#pragma unroll
+        for (int r = 0; r < E; ++r) k[r] = S[phys<LE>(pos_of<BT, LE>(t, r))];
+    }
+
+    // levels HI..LO (position bits) with register window at B
+    template <int B, int HI, int LO>
+    static __device__ __forceinline__ void levels(double (&k)[E]) {
+#pragma unroll
+        for (int j = HI; j >= LO; --j) {
+            const int jr = j - B;
+#pragma unroll
+            for (int r = 0; r < E; ++r)
+                if (!((r >> jr) & 1)) cmpx(k[r], k[r | (1 << jr)]);
+        }
+    }
+
+    template <int S, int K, int BPREV>
+    static __device__ __forceinline__ void windows(double (&k)[E], double *Sm, int t) {
+        constexpr int B = wb(S, K);
+        constexpr int HI = (K == 0) ? S - 1 : BPREV - 1;
+        if constexpr (B != BPREV) transpose<BPREV, B>(k, Sm, t);
+        levels<B, HI, B>(k);
+        if constexpr (B > 0) windows<S, K + 1, B>(k, Sm, t);
+    }
+
+    template <int S>
+    static __device__ __forceinline__ void stage(double (&k)[E], double *Sm, int t) {
+        // stored = (-1)^g(p) * x with g_S(p) = bit S of p (0 for the last stage): flip where g changes
+#pragma unroll
+        for (int r = 0; r < E; ++r) {
+            int p = t * E + r;
+            unsigned gs = (S < LN) ? ((p >> S) & 1) : 0;
+            unsigned gp = (S > 1) ? ((p >> (S - 1)) & 1) : 0;
+            k[r] = flip_sign(k[r], (gs ^ gp) << 31);
+        }
+        windows<S, 0, 0>(k, Sm, t);
+        if constexpr (S < LN) stage<S + 1>(k, Sm, t);
+    }
+
+    static __device__ __forceinline__ void sort(double (&k)[E], double *Sm, int t) { stage<1>(k, Sm, t); }
+};
+
+// grid = G persistent workgroups; workgroup g owns timepoints g, g+G, ...
+// partial[(g*(J-1) + j)*n + i] = sum over its timepoints of the band counts of curve i
+template <int NT, int E, int J>
+__global__ __launch_bounds__(NT) void mbd_rank_kernel(const double *__restrict__ Y, i64 T, i64 n,
+                                                      u64 *__restrict__ partial) {
+    using C = RankCfg<NT, E>;
+    constexpr int N = C::N;
+    constexpr int LE = C::LE;
+    extern __shared__ double Sm[];
+    __shared__ u32 s_nnan;
+    const int t = threadIdx.x;
+    u64 acc[E][JMAX - 1];
+#pragma unroll
+    for (int e = 0; e < E; ++e)
+#pragma unroll
+        for (int j = 0; j < J - 1; ++j) acc[e][j] = 0;
+    const double INF = __builtin_huge_val();
+    const u32 npad = (u32)(N - n);
+
+    for (i64 tp = blockIdx.x; tp < T; tp += gridDim.x) {
+        const double *__restrict__ row = Y + tp * n;
+        if (t == 0) s_nnan = 0;
+        double k[E];
+        u32 mynan = 0;
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            i64 i = (i64)t + (i64)e * NT;
+            double v = (i < n) ? row[i] : INF;
+            if (v != v) { v = INF; ++mynan; }
+            k[e] = v;
+        }
+        __syncthreads();                       // s_nnan zeroed; previous row's searches finished
+        if (mynan) atomicAdd(&s_nnan, mynan);
+        RankSorter<NT, E>::sort(k, Sm, t);
+#pragma unroll
+        for (int r = 0; r < E; ++r) Sm[phys<LE>(t * E + r)] = k[r];
+        __syncthreads();
+        const u32 nnan = s_nnan;
+        // look every own curve up in the sorted row
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            i64 i = (i64)t + (i64)e * NT;
+            if (i < n) {
+                double x = row[i];
+                if (x == x) {
+                    int lo = 0, hi = 0;
+#pragma unroll
+                    for (int s = N >> 1; s >= 1; s >>= 1) {
+                        double a = Sm[phys<LE>(lo + s - 1)];
+                        double b = Sm[phys<LE>(hi + s - 1)];
+                        lo += (a < x) ? s : 0;
+                        hi += (b <= x) ? s : 0;
+                    }
+                    hi += (Sm[phys<LE>(hi)] <= x) ? 1 : 0;
+                    u32 B = (u32)lo;
+                    u32 A = (x == INF) ? 0u : (u32)(N - hi) - npad - nnan;
+                    band_counts_add<J>(A, B, nnan, (u64)(n - 1), acc[e]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        i64 i = (i64)t + (i64)e * NT;
+        if (i < n) {
+#pragma unroll
+            for (int j = 0; j < J - 1; ++j) partial[((size_t)blockIdx.x * (J - 1) + j) * n + i] = acc[e][j];
+        }
+    }
+}
+
+// out[q*(J-1)+j] = sum_g partial[g][j][targets[q]]
+__global__ __launch_bounds__(256) void rank_reduce_kernel(const u64 *__restrict__ partial, int G, i64 n, int jc,
+                                                          const i64 *__restrict__ targets, i64 m,
+                                                          u64 *__restrict__ out) {
+    i64 q = (i64)blockIdx.x * 256 + threadIdx.x;
+    if (q >= m) return;
+    i64 i = targets ? targets[q] : q;
+    for (int j = 0; j < jc; ++j) {
+        u64 s = 0;
+        for (int g = 0; g < G; ++g) s += partial[((size_t)g * jc + j) * n + i];
+        out[q * jc + j] = s;
+    }
+}
+
+static int rank_grid(i64 T) {
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+    }
+    i64 g = T < cus ? T : cus;
+    if (g > RK_MAXG) g = RK_MAXG;
+    return (int)g;
+}
+
+bool mbd_rank_supported(i64 T, i64 n, int J) {
+    (void)T;
+    return n >= 2 && n <= 16384 && (J == 2 || J == 3);
+}
+
+size_t mbd_rank_workspace_bytes(i64 T, i64 n, int J) {
+    if (!mbd_rank_supported(T, n, J)) return 0;
+    i64 g = T < RK_MAXG ? T : RK_MAXG;
+    return (size_t)g * (J - 1) * n * 8;
+}
+
+template <int NT, int E, int J>
+static int launch_rank_cfg(const double *Y, i64 T, i64 n, u64 *partial, int G, hipStream_t s) {
+    using C = RankCfg<NT, E>;
+    auto kern = mbd_rank_kernel<NT, E, J>;
+    SD_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES));
+    hipLaunchKernelGGL(kern, dim3(G), dim3(NT), C::LDS_BYTES, s, Y, T, n, partial);
+    SD_HIP(hipGetLastError());
+    return SD_OK;
+}
+
+template <int J>
+static int launch_rank_j(const double *Y, i64 T, i64 n, u64 *partial, int G, hipStream_t s) {
+    if (n <= 1024) return launch_rank_cfg<256, 4, J>(Y, T, n, partial, G, s);
+    if (n <= 2048) return launch_rank_cfg<256, 8, J>(Y, T, n, partial, G, s);
+    if (n <= 4096) return launch_rank_cfg<1024, 4, J>(Y, T, n, partial, G, s);
+    if (n <= 8192) return launch_rank_cfg<1024, 8, J>(Y, T, n, partial, G, s);
+    return launch_rank_cfg<1024, 16, J>(Y, T, n, partial, G, s);
+}
+
+int launch_mbd_rank(const double *Y, i64 T, i64 n, const i64 *targets, i64 m, int J,
+                    u64 *out, void *ws, size_t ws_bytes, hipStream_t s) {
+    if (!mbd_rank_supported(T, n, J)) return fail(SD_ERR_UNSUPPORTED, "rank kernel covers 2 <= n <= 16384, J in {2,3}");
+    int G = rank_grid(T);
+    size_t need = (size_t)G * (J - 1) * n * 8;
+    if (!ws || ws_bytes < need) return fail(SD_ERR_WORKSPACE, "rank workspace too small");
+    u64 *partial = (u64 *)ws;
+    int rc = (J == 2) ? launch_rank_j<2>(Y, T, n, partial, G, s) : launch_rank_j<3>(Y, T, n, partial, G, s);
+    if (rc) return rc;
+    hipLaunchKernelGGL(rank_reduce_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s, partial, G, n, J - 1,
+                       targets, m, out);
+    SD_HIP(hipGetLastError());
+    return SD_OK;
+}
+
+}  // namespace sd

@@ -1,0 +1,255 @@
+// simplex.hip -- K4: batched point-in-simplex containment counts.
+//
+// Replaces _is_in_simplex (_containment.py:138-176; an LP feasibility problem handed
+// to scipy.optimize.linprog: sum l_k p_k = x, sum l_k = 1, l >= 0) inside the subset
+// loops of _pointwisedepth (_pointcloud.py:50-54) and _simplex_depth /
+// _simplex_containment (_functional.py:281-285, _containment.py:130-136).
+//
+// point_in_hull() is the same restatement as oracle_point_in_hull (oracle/oracle.c):
+// complete-pivoting elimination of [P^T;1] l = [x;1]; full rank -> unique l, inside
+// iff min l >= -tol; rank deficient (degenerate simplex) -> enumerate `rank`-subsets
+// (Caratheodory).  Same operation order as the oracle so decisions agree bit for bit
+// (this file is compiled with -ffp-contract=off).
+//
+// Work decomposition: threads own contiguous ranges of the lexicographic subset
+// enumeration (unrank once, then step), or one sampled subset each in the sampled
+// estimators.  Small dense fp64 systems per thread: VALU bound, no MFMA (systems are
+// (d+1)x(d+1) with d <= 8 and data-dependent pivoting).
+#include "sd_common.h"
+
+namespace sd {
+
+constexpr int SMAX = 10;   // d + 1 <= 9
+constexpr int SX_THREADS = 256;
+
+__device__ static bool solve_subset(const double (*R)[SMAX + 1], int rank, const int *cols, double tol,
+                                    double rank_eps) {
+    double A[SMAX][SMAX + 1];
+    for (int r = 0; r < rank; ++r) {
+        for (int c = 0; c < rank; ++c) A[r][c] = R[r][cols[c]];
+        A[r][rank] = R[r][SMAX];
+    }
+    for (int c = 0; c < rank; ++c) {
+        int p = c;
+        double best = fabs(A[c][c]);
+        for (int r = c + 1; r < rank; ++r)
+            if (fabs(A[r][c]) > best) { best = fabs(A[r][c]); p = r; }
+        if (best <= rank_eps) return false;
+        if (p != c)
+            for (int k = 0; k <= rank; ++k) { double tmp = A[c][k]; A[c][k] = A[p][k]; A[p][k] = tmp; }
+        for (int r = c + 1; r < rank; ++r) {
+            double f = A[r][c] / A[c][c];
+            for (int k = c; k <= rank; ++k) A[r][k] -= f * A[c][k];
+        }
+    }
+    double l[SMAX];
+    for (int c = rank - 1; c >= 0; --c) {
+        double s = A[c][rank];
+        for (int k = c + 1; k < rank; ++k) s -= A[c][k] * l[k];
+        l[c] = s / A[c][c];
+    }
+    for (int c = 0; c < rank; ++c)
+        if (!(l[c] >= -tol)) return false;
+    return true;
+}
+
+// pts: kpts x d (row-major, local), x: d
+__device__ static bool point_in_hull(const double *pts, int kpts, int d, const double *x, double tol) {
+    int rows = d + 1;
+    double R[SMAX][SMAX + 1];
+    double scale = 1.0;
+    for (int r = 0; r < d; ++r) {
+        for (int c = 0; c < kpts; ++c) {
+            double v = pts[c * d + r];
+            if (v != v) return false;
+            R[r][c] = v;
+            if (fabs(v) > scale) scale = fabs(v);
+        }
+        if (x[r] != x[r]) return false;
+        R[r][SMAX] = x[r];
+        if (fabs(x[r]) > scale) scale = fabs(x[r]);
+    }
+    for (int c = 0; c < kpts; ++c) R[d][c] = 1.0;
+    R[d][SMAX] = 1.0;
+    if (isinf(scale)) return false;
+    double rank_eps = 1e-10 * scale;
+    int rank = 0;
+    int lim = rows < kpts ? rows : kpts;
+    for (; rank < lim; ++rank) {
+        int pr = -1, pc = -1;
+        double best = rank_eps;
+        for (int r = rank; r < rows; ++r)
+            for (int c = rank; c < kpts; ++c)
+                if (fabs(R[r][c]) > best) { best = fabs(R[r][c]); pr = r; pc = c; }
+        if (pr < 0) break;
+        if (pr != rank)
+            for (int k = 0; k <= SMAX; ++k) { double tmp = R[rank][k]; R[rank][k] = R[pr][k]; R[pr][k] = tmp; }
+        if (pc != rank)
+            for (int r = 0; r < rows; ++r) { double tmp = R[r][rank]; R[r][rank] = R[r][pc]; R[r][pc] = tmp; }
+        for (int r = rank + 1; r < rows; ++r) {
+            double f = R[r][rank] / R[rank][rank];
+            if (f != 0.0) {
+                for (int c = rank; c < kpts; ++c) R[r][c] -= f * R[rank][c];
+                R[r][SMAX] -= f * R[rank][SMAX];
+            }
+        }
+    }
+    for (int r = rank; r < rows; ++r)
+        if (fabs(R[r][SMAX]) > 1e-7 * scale) return false;
+    int cols[SMAX];
+    for (int c = 0; c < rank; ++c) cols[c] = c;
+    if (rank == kpts) return solve_subset(R, rank, cols, tol, rank_eps);
+    for (;;) {
+        if (solve_subset(R, rank, cols, tol, rank_eps)) return true;
+        int k = rank - 1;
+        while (k >= 0 && cols[k] == kpts - rank + k) --k;
+        if (k < 0) break;
+        ++cols[k];
+        for (int l = k + 1; l < rank; ++l) cols[l] = cols[l - 1] + 1;
+    }
+    return false;
+}
+
+__device__ static u64 binom_dev(u64 a, int k) {
+    if (k < 0 || (u64)k > a) return 0;
+    u64 c = 1;
+    for (int j = 1; j <= k; ++j) c = c * (a - (u64)j + 1) / (u64)j;
+    return c;
+}
+
+// lexicographic unranking of the r-th k-subset of {0..no-1}
+__device__ static void unrank_comb(u64 r, int k, i64 no, i64 *idx) {
+    i64 c = 0;
+    for (int p = 0; p < k; ++p) {
+        for (;; ++c) {
+            u64 cnt = binom_dev((u64)(no - 1 - c), k - 1 - p);   // subsets starting with c at position p
+            if (r < cnt) break;
+            r -= cnt;
+        }
+        idx[p] = c++;
+    }
+}
+
+__device__ static bool next_comb(i64 *idx, int k, i64 no) {
+    int i = k - 1;
+    while (i >= 0 && idx[i] == no - k + i) --i;
+    if (i < 0) return false;
+    ++idx[i];
+    for (int l = i + 1; l < k; ++l) idx[l] = idx[l - 1] + 1;
+    return true;
+}
+
+// splitmix64 finaliser: counter-based draws keyed by (seed, target, sample, draw)
+__device__ __host__ static inline u64 mix64(u64 z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+// draw k distinct indices in [0,no) for (seed, tg, sample): rejection on duplicates,
+// result sorted ascending.  Restated identically in oracle.c (oracle_sample_subset).
+__device__ static void sample_subset(u64 seed, u64 tg, u64 sample, int k, i64 no, i64 *idx) {
+    u64 key = mix64(seed ^ mix64(tg * 0xD1342543DE82EF95ull + sample));
+    u64 ctr = 0;
+    for (int p = 0; p < k;) {
+        u64 r = mix64(key + ctr++);
+        i64 c = (i64)(r % (u64)no);
+        bool dup = false;
+        for (int l = 0; l < p; ++l) dup |= (idx[l] == c);
+        if (!dup) idx[p++] = c;
+    }
+    for (int a = 1; a < k; ++a) {   // insertion sort
+        i64 v = idx[a];
+        int b = a - 1;
+        while (b >= 0 && idx[b] > v) { idx[b + 1] = idx[b]; --b; }
+        idx[b + 1] = v;
+    }
+}
+
+__device__ __forceinline__ u64 block_sum_u64(u64 v, u64 *scratch) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+    if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = v;
+    __syncthreads();
+    u64 r = 0;
+    if (threadIdx.x == 0)
+        for (int k = 0; k < SX_THREADS / 64; ++k) r += scratch[k];
+    return r;
+}
+
+// grid = (chunks, m).  T == 0 selects the pointcloud form (P is n x d);
+// otherwise P is n x T x d and c counts timepoints (relax / strict reduction).
+__global__ __launch_bounds__(SX_THREADS) void simplex_kernel(
+    const double *__restrict__ P, i64 n, i64 T, int d, const i64 *__restrict__ targets, int relax, double tol,
+    u64 total, u64 per_thread, i64 samples, u64 seed, i64 q0, u64 *__restrict__ out) {
+    __shared__ u64 scratch[SX_THREADS / 64];
+    i64 q = q0 + blockIdx.y;
+    i64 tg = targets ? targets[q] : q;
+    int k = d + 1;
+    i64 no = n - 1;
+    u64 tid = (u64)blockIdx.x * SX_THREADS + threadIdx.x;
+    u64 first = tid * per_thread;
+    u64 acc = 0;
+    if (first < total) {
+        u64 last = first + per_thread < total ? first + per_thread : total;
+        i64 idx[SMAX];
+        double pts[SMAX * 8], x[8];
+        if (samples < 0) unrank_comb(first, k, no, idx);
+        i64 TT = T > 0 ? T : 1;
+        for (u64 r = first; r < last; ++r) {
+            if (samples >= 0) sample_subset(seed, (u64)tg, r, k, no, idx);
+            u64 cnt = 0;
+            for (i64 t = 0; t < TT; ++t) {
+                for (int c = 0; c < k; ++c) {
+                    i64 src = idx[c] < tg ? idx[c] : idx[c] + 1;     // skip the target itself
+                    const double *pp = P + (src * TT + t) * d;
+                    for (int e = 0; e < d; ++e) pts[c * d + e] = pp[e];
+                }
+                const double *xx = P + (tg * TT + t) * d;
+                for (int e = 0; e < d; ++e) x[e] = xx[e];
+                cnt += point_in_hull(pts, k, d, x, tol);
+            }
+            acc += (T > 0 && !relax) ? (cnt / (u64)TT) : cnt;
+            if (samples < 0 && r + 1 < last) next_comb(idx, k, no);
+        }
+    }
+    u64 tot = block_sum_u64(acc, scratch);
+    if (threadIdx.x == 0 && tot) atomicAdd(&out[q], tot);
+}
+
+static int launch_simplex_common(const double *P, i64 n, i64 T, int d, const i64 *targets, i64 m, int relax,
+                                 double tol, i64 samples, u64 seed, u64 *out, hipStream_t s) {
+    SD_HIP(hipMemsetAsync(out, 0, sizeof(u64) * m, s));
+    u64 total;
+    if (samples >= 0) total = (u64)samples;
+    else if (!binom_u64_checked((u64)(n - 1), d + 1, &total)) return fail(SD_ERR_OVERFLOW, "subset count overflow");
+    if (total == 0) return SD_OK;
+    // aim for ~2^18 threads over all targets, at least 1 subset per thread
+    u64 want_threads = ((u64)1 << 18) / (u64)(m > 0 ? m : 1);
+    if (want_threads < SX_THREADS) want_threads = SX_THREADS;
+    u64 per_thread = (total + want_threads - 1) / want_threads;
+    if (per_thread < 1) per_thread = 1;
+    u64 threads = (total + per_thread - 1) / per_thread;
+    u64 blocks = (threads + SX_THREADS - 1) / SX_THREADS;
+    if (blocks > 0x7fffffffull) return fail(SD_ERR_UNSUPPORTED, "too many subsets per target for one launch");
+    for (i64 q0 = 0; q0 < m; q0 += 65535) {   // grid.y limit: fold large m into several launches
+        i64 mm = m - q0 < 65535 ? m - q0 : 65535;
+        dim3 grid((unsigned)blocks, (unsigned)mm);
+        hipLaunchKernelGGL(simplex_kernel, grid, dim3(SX_THREADS), 0, s, P, n, T, d, targets, relax, tol, total,
+                           per_thread, samples, seed, q0, out);
+    }
+    SD_HIP(hipGetLastError());
+    return SD_OK;
+}
+
+int launch_pointcloud_simplex(const double *P, i64 n, int d, const i64 *targets, i64 m, double tol,
+                              i64 samples, u64 seed, u64 *out, hipStream_t s) {
+    return launch_simplex_common(P, n, 0, d, targets, m, 1, tol, samples, seed, out, s);
+}
+
+int launch_multi_simplex(const double *P, i64 n, i64 T, int d, const i64 *targets, i64 m, int relax,
+                         double tol, i64 samples, u64 seed, u64 *out, hipStream_t s) {
+    return launch_simplex_common(P, n, T, d, targets, m, relax, tol, samples, seed, out, s);
+}
+
+}  // namespace sd

@@ -1,0 +1,150 @@
+"""Functional (band) depth drivers on the HIP engine.
+
+Mirrors statdepth/depth/calculations/_functional.py: `_functionaldepth` (:17-97),
+`_samplefunctionaldepth` (:99-196).  The per-target subset enumeration of
+`_univariate_band_depth` (:198-255) and `_simplex_depth` (:257-286) is replaced by
+calls into libstatdepth_hip (statdepth_amd.engine); the float normalisers stay here,
+in fp64, written as the reference writes them.
+"""
+from itertools import combinations
+from typing import List, Union
+
+import numpy as np
+import pandas as pd
+from scipy.special import binom
+
+from ... import engine
+from ._containment import _select_containment
+from ._helper import DepthDegeneracy, _handle_depth_errors
+
+__all__ = ['_functionaldepth', '_samplefunctionaldepth']
+
+
+def _positions(df: pd.DataFrame, labels) -> np.ndarray:
+    """Column positions of `labels` (the reference addresses targets by label, :232)."""
+    pos = df.columns.get_indexer(list(labels))
+    if (pos < 0).any():
+        missing = [l for l, p in zip(labels, pos) if p < 0]
+        raise KeyError(f'{missing} not in columns')
+    return pos.astype(np.int64)
+
+
+def _univariate_depths(df: pd.DataFrame, cols, J: int, relax: bool, device=None, algo='auto') -> np.ndarray:
+    """Band depth of columns `cols` of `df` (rows = timepoints): sum_j S_nj / binom(n, j).
+
+    n = number of columns INCLUDING the target (:229) while bands come from the other
+    n-1 (:235,243); S_nj = (sum_t contained j-bands)/T for relax (_containment.py:80
+    `c/T`) or the number of j-bands containing the curve at every t (`c//T`).
+    """
+    X = df.to_numpy(dtype=np.float64, copy=False)      # keeps the frame's memory layout
+    T, n = X.shape
+    tg = _positions(df, cols)
+    if relax:
+        counts = engine.mbd_counts(X, tg, J=J, algo=algo, device=device).astype(np.float64) / T
+    else:
+        if J > 4:
+            raise NotImplementedError('strict band depth (relax=False) is implemented for J <= 4')
+        counts = engine.bd_strict_counts(X, tg, J=J, device=device).astype(np.float64)
+    depth = np.zeros(len(tg), dtype=np.float64)
+    for j in range(2, J + 1):
+        depth += counts[:, j - 2] / binom(n, j)        # (:253)
+    return depth
+
+
+def _callable_band_depth(data: pd.DataFrame, curve, relax: bool, containment, J: int) -> float:
+    """Generic enumerator for a user-supplied containment callable (:228-255).
+
+    Not the hot path: arbitrary Python cannot run on the GPU, so the plug-in protocol
+    of docs/index.md:124-148 is honoured on the host, one call per subset.
+    """
+    band_depth = 0
+    n = data.shape[1]
+    curvedata = data.loc[:, curve]
+    data = data.drop(curve, axis=1)
+    for j in range(2, J + 1):
+        S_nj = 0
+        for sequence in combinations(list(data.columns), j):
+            S_nj += containment(data=data.loc[:, list(sequence)], curve=curvedata, relax=relax)
+        band_depth += S_nj / binom(n, j)
+    return band_depth
+
+
+def _curves_tensor(data: List[pd.DataFrame]) -> np.ndarray:
+    """list of n frames (T x d) -> (n, T, d) fp64."""
+    return np.stack([np.asarray(df.to_numpy(dtype=np.float64)) for df in data])
+
+
+def _functionaldepth(data: List[pd.DataFrame], to_compute: Union[list, pd.Index] = None, J=2, containment='r2',
+                     relax=False, deep_check=False, quiet=True, device=None, algo='auto') -> pd.Series:
+    _handle_depth_errors(data=data, J=J, containment=containment, relax=relax, deep_check=deep_check)
+    cdef = _select_containment(containment=containment)
+
+    if len(data) == 1:                                   # real-valued case by assumption (:60-61)
+        if cdef == 'simplex':
+            cdef = 'r2'                                  # (:62-63)
+        df = data[0]
+        cols = df.columns if to_compute is None else to_compute     # (:68-71)
+        if cdef == 'r2':
+            depths = _univariate_depths(df, cols, J, relax, device=device, algo=algo)
+        elif cdef == 'r2_enum':
+            raise NotImplementedError                    # _containment.py:103
+        else:
+            depths = [_callable_band_depth(df, col, relax, cdef, J) for col in cols]
+        return pd.Series(index=cols, data=depths)        # (:78)
+
+    # multivariate case (:79-95)
+    if cdef == 'simplex':
+        f = [i for i in range(len(data))] if to_compute is None else to_compute
+        P = _curves_tensor(data)
+        n, T, d = P.shape
+        counts = engine.multi_simplex_counts(P, np.asarray(list(f), dtype=np.int64), relax=relax,
+                                             device=device).astype(np.float64)
+        if relax:
+            counts = counts / T                          # _containment.py:136
+        depths = counts / binom(n - 1, d + 1)            # (:278,286): n there = number of OTHERS
+        return pd.Series(index=f, data=depths)
+    if cdef == 'r2_enum':
+        raise NotImplementedError                        # _containment.py:83-103
+    raise NotImplementedError('custom containment callables are only supported for univariate data')
+
+
+def _samplefunctionaldepth(data: List[pd.DataFrame], K: int, to_compute: Union[list, pd.Index] = None, J=2,
+                           containment='r2', relax=False, deep_check=False, quiet=True, device=None,
+                           algo='auto') -> pd.Series:
+    """K-block sampled band depth (:99-196).
+
+    Block selection is host logic and consumes the global numpy RNG exactly as the
+    reference does (`df.sample(n=ss, axis=1)`, :176), so `np.random.seed` reproduces the
+    reference's blocks; each block's depth is one device call.
+    """
+    samples = []
+    _handle_depth_errors(data=data, J=J, containment=containment, relax=relax, deep_check=deep_check)
+    cdef = _select_containment(containment=containment)
+    if len(data) != 1:
+        return pd.Series(dtype=np.float64)               # reference stub returns an empty list (:187-196)
+
+    df = data[0]
+    cols = df.columns if to_compute is None else to_compute
+    orig = df.loc[:, cols]                               # (:161)
+    ss = df.shape[1] // K                                # (:162)
+    if ss == 0:
+        raise DepthDegeneracy(f'Block size {K} is too large, not enough functions to sample.')
+    if cdef == 'simplex':
+        cdef = 'r2'
+    if cdef == 'r2_enum':
+        raise NotImplementedError
+
+    for col in orig.columns:
+        depths = []
+        for _ in range(K):
+            t = df.sample(n=ss, axis=1)                  # (:176) global numpy RNG
+            df = df.drop(t.columns, axis=1)              # (:177) without replacement across blocks
+            t = t.copy()
+            t.loc[:, col] = orig.loc[:, col]             # (:178) force the target into the block
+            if cdef == 'r2':
+                depths.append(_univariate_depths(t, [col], J, relax, device=device, algo='pairwise')[0])
+            else:
+                depths.append(_callable_band_depth(t, col, relax, cdef, J))
+        samples.append(np.mean(depths))                  # (:182)
+        df = orig.copy()                                 # (:183) -- the pool shrinks to `cols`, as in the reference
+    return pd.Series(index=df.columns, data=samples)     # (:186)

@@ -1,0 +1,116 @@
+"""Public factories and result objects (reference: statdepth/depth/depth.py).
+
+`FunctionalDepth` (:362-402) and `PointcloudDepth` (:347-359) keep the reference's
+signatures; `device=` and `algo=` are keyword-only additions.  Result classes keep
+the reference's method names and conventions (:14-65,178-185,337-341).  The plotly
+drawing helpers of the reference (:91-175,193-335) are visualisation, not part of
+the hot path, and are not provided.
+"""
+from typing import List
+
+import pandas as pd
+
+from .abstract import AbstractDepth
+from .calculations._functional import _functionaldepth, _samplefunctionaldepth
+from .calculations._helper import DepthDegeneracy   # noqa: F401
+from .calculations._pointcloud import _pointwisedepth, _samplepointwisedepth
+
+__all__ = ['FunctionalDepth', 'PointcloudDepth']
+
+
+class _FunctionalDepthSeries(AbstractDepth, pd.Series):
+    """Depth values as a Series that also remembers its data (:14-65)."""
+
+    def __init__(self, df: pd.DataFrame, depths: pd.Series):
+        super().__init__(data=depths)
+        # plain attributes, like the reference: a reference to the frame, not a copy (:19)
+        object.__setattr__(self, '_orig_data', df)
+        object.__setattr__(self, '_depths', depths)
+        object.__setattr__(self, '_ordered_depths', None)
+
+    def ordered(self, ascending=False) -> pd.Series:
+        '''Sort by depth, deepest first (:23-27).'''
+        if self._ordered_depths is None:
+            object.__setattr__(self, '_ordered_depths', self._depths.sort_values(ascending=ascending))
+        return self._ordered_depths
+
+    def deepest(self, n=1) -> pd.Series:
+        '''The n deepest items (:29-37).'''
+        if self._ordered_depths is None:
+            object.__setattr__(self, '_ordered_depths', self._depths.sort_values(ascending=False))
+        if n == 1:
+            return pd.Series(index=[list(self._ordered_depths.index)[0]], data=[self._ordered_depths.values[0]])
+        return pd.Series(index=self._ordered_depths.index[0: n], data=self._ordered_depths.values[0: n])
+
+    def outlying(self, n=1) -> pd.Series:
+        '''The n most outlying items (:39-46).'''
+        if self._ordered_depths is None:
+            object.__setattr__(self, '_ordered_depths', self._depths.sort_values(ascending=False))
+        if n == 1:
+            return pd.Series(index=[list(self._ordered_depths.index)[-1]], data=[self._ordered_depths.values[-1]])
+        return pd.Series(index=self._ordered_depths.index[-n:], data=self._ordered_depths.values[-n:])
+
+    def sorted(self, ascending=False):
+        return self.ordered(ascending=ascending)
+
+    def median(self):
+        return self.deepest(n=1)
+
+    def quartile(self, ratio=0.5):
+        # the reference ignores `ratio` and always takes the lower half (:55-56)
+        return self._depths.sort_values().head(int(self._depths.shape[0] * 0.5))
+
+    def get_depths(self):
+        return self._depths
+
+    def get_data(self):
+        return self._orig_data
+
+    def depths(self):
+        return self.get_depths()
+
+
+class _FunctionalDepthUnivariate(_FunctionalDepthSeries):
+    '''Univariate curves are the COLUMNS of the frame (:178-185).'''
+
+    def drop_outlying_data(self, n=1) -> pd.DataFrame:
+        return self._orig_data.drop(self.outlying(n=n).index, axis=1)
+
+    def get_deepest_data(self, n=1) -> pd.DataFrame:
+        return self._orig_data.loc[:, self.deepest(n=n).index]
+
+    def get_outlying_data(self, n=1) -> pd.DataFrame:
+        return self._orig_data.loc[:, self.outlying(n=n).index]
+
+
+class _PointwiseDepth(_FunctionalDepthSeries):
+    '''Points are the ROWS of the frame (:337-341).'''
+
+    def drop_outlying_data(self, n=1) -> pd.DataFrame:
+        return self._orig_data.drop(self.outlying(n=n).index, axis=0)
+
+    def get_deepest_data(self, n=1) -> pd.DataFrame:
+        return self._orig_data.loc[self.deepest(n=n).index, :]
+
+
+def PointcloudDepth(data: pd.DataFrame, to_compute: pd.Index = None, K=None, containment='simplex', quiet=True,
+                    *, device=None) -> _PointwiseDepth:
+    if K is not None:
+        depth = _samplepointwisedepth(data=data, to_compute=to_compute, K=K, containment=containment,
+                                      device=device)
+    else:
+        depth = _pointwisedepth(data=data, to_compute=to_compute, containment=containment, device=device)
+    return _PointwiseDepth(df=data, depths=depth)
+
+
+def FunctionalDepth(data: List[pd.DataFrame], to_compute=None, K=None, J=2, containment='r2', relax=False,
+                    deep_check=False, quiet=True, *, device=None, algo='auto'):
+    if K is not None:
+        depth = _samplefunctionaldepth(data=data, to_compute=to_compute, K=K, J=J, containment=containment,
+                                       relax=relax, deep_check=deep_check, quiet=quiet, device=device, algo=algo)
+    else:
+        depth = _functionaldepth(data=data, to_compute=to_compute, J=J, containment=containment, relax=relax,
+                                 deep_check=deep_check, quiet=quiet, device=device, algo=algo)
+    if len(data) == 1:                                   # univariate by assumption (:399-400)
+        return _FunctionalDepthUnivariate(df=data[0], depths=depth)
+    return _FunctionalDepthSeries(df=data[0], depths=depth)   # multivariate (:401-402)

@@ -1,0 +1,196 @@
+"""Host-side driver of the HIP kernels: ndarray / torch tensor in, integer counts out.
+
+Everything numerical happens in libstatdepth_hip.so; this module moves data to HBM
+(torch is the allocator / stream provider), sizes workspaces and calls the C ABI.
+"""
+import numpy as np
+
+from . import _native
+from ._native import ALGOS, check
+
+_torch = None
+
+
+def torch():
+    global _torch
+    if _torch is None:
+        import torch as t
+        _torch = t
+    return _torch
+
+
+def _device(device=None):
+    t = torch()
+    _native.require_device()
+    if not t.cuda.is_available():
+        raise RuntimeError("statdepth_amd: torch reports no ROCm device")
+    if device is None:
+        return t.device("cuda", t.cuda.current_device())
+    return t.device(device)
+
+
+def _stream_ptr(dev):
+    return torch().cuda.current_stream(dev).cuda_stream
+
+
+class DeviceMatrix:
+    """A T x n fp64 data set resident in HBM in one of the two pandas layouts.
+
+    `tensor` is a 2-D torch tensor whose logical shape is (T, n); strides (in
+    elements) describe either layout, exactly what sd_* expect as (st, sn).
+    """
+
+    def __init__(self, tensor):
+        t = torch()
+        assert tensor.dim() == 2 and tensor.dtype == t.float64 and tensor.is_cuda
+        st, sn = tensor.stride()
+        T, n = tensor.shape
+        if not ((sn == 1 and st == n) or (st == 1 and sn == T) or T == 1 or n == 1):
+            tensor = tensor.contiguous()
+            st, sn = tensor.stride()
+        if n == 1 or T == 1:      # degenerate strides: normalise to time-major
+            tensor = tensor.contiguous()
+            st, sn = n, 1
+        self.tensor = tensor
+        self.T, self.n, self.st, self.sn = int(T), int(n), int(st), int(sn)
+
+    @property
+    def device(self):
+        return self.tensor.device
+
+
+def to_device_matrix(X, device=None):
+    """ndarray (T, n) in either memory order, or a CUDA tensor -> DeviceMatrix (no layout change)."""
+    t = torch()
+    if isinstance(X, DeviceMatrix):
+        return X
+    if isinstance(X, t.Tensor):
+        if not X.is_cuda:
+            X = X.to(_device(device))
+        return DeviceMatrix(X.to(t.float64))
+    dev = _device(device)
+    A = np.asarray(X, dtype=np.float64)
+    if A.ndim != 2:
+        raise ValueError("expected a 2-D array (timepoints x curves)")
+    if A.flags.c_contiguous or not A.flags.f_contiguous:
+        A = np.ascontiguousarray(A)
+        return DeviceMatrix(t.from_numpy(A).to(dev))
+    # F-contiguous (column-built DataFrame): ship the bytes as they lie, view as (T, n)
+    return DeviceMatrix(t.from_numpy(A.T).to(dev).t())
+
+
+def _targets_dev(targets, n, dev):
+    t = torch()
+    if targets is None:
+        return None, n, 0
+    tg = np.ascontiguousarray(np.asarray(targets, dtype=np.int64))
+    if tg.ndim != 1:
+        raise ValueError("targets must be 1-D")
+    if len(tg) and (tg.min() < 0 or tg.max() >= n):
+        raise IndexError("target index out of range")
+    td = t.from_numpy(tg).to(dev)
+    return td, len(tg), td.data_ptr()
+
+
+def mbd_counts(X, targets=None, J=2, algo="auto", device=None, return_tensor=False):
+    """int64[m, J-1]: sum over t of contained j-bands per target (sd_mbd_counts)."""
+    t = torch()
+    lib = _native.require_device()
+    M = to_device_matrix(X, device)
+    dev = M.device
+    td, m, tp = _targets_dev(targets, M.n, dev)
+    a = ALGOS[algo] if isinstance(algo, str) else int(algo)
+    out = t.empty((m, J - 1), dtype=t.int64, device=dev)
+    wsb = lib.sd_mbd_workspace_bytes(M.T, M.n, M.st, M.sn, m, J, a)
+    ws = t.empty(max(int(wsb), 8), dtype=t.uint8, device=dev)
+    check(lib.sd_mbd_counts(M.tensor.data_ptr(), M.T, M.n, M.st, M.sn, tp, m, J, a,
+                            out.data_ptr(), ws.data_ptr(), wsb, _stream_ptr(dev)))
+    if return_tensor:
+        return out
+    return out.cpu().numpy()
+
+
+def above_below(X, targets=None, device=None):
+    """uint32 -> int64 [m, T, 2] strictly-above / strictly-below counts (sd_above_below)."""
+    t = torch()
+    lib = _native.require_device()
+    M = to_device_matrix(X, device)
+    dev = M.device
+    td, m, tp = _targets_dev(targets, M.n, dev)
+    out = t.empty((m, M.T, 2), dtype=t.int32, device=dev)
+    wsb = M.T * M.n * 8 + 1024
+    ws = t.empty(wsb, dtype=t.uint8, device=dev)
+    check(lib.sd_above_below(M.tensor.data_ptr(), M.T, M.n, M.st, M.sn, tp, m, out.data_ptr(),
+                             ws.data_ptr(), wsb, _stream_ptr(dev)))
+    return out.cpu().numpy().astype(np.int64) & 0xFFFFFFFF
+
+
+def bd_strict_counts(X, targets=None, J=2, device=None):
+    """int64[m, J-1]: j-subsets whose band contains the target at every t (sd_bd_strict_j_counts)."""
+    t = torch()
+    lib = _native.require_device()
+    M = to_device_matrix(X, device)
+    dev = M.device
+    td, m, tp = _targets_dev(targets, M.n, dev)
+    out = t.empty((m, J - 1), dtype=t.int64, device=dev)
+    wsb = lib.sd_bd_strict_j_workspace_bytes(M.T, M.n, M.st, M.sn, m, J)
+    ws = t.empty(max(int(wsb), 8), dtype=t.uint8, device=dev)
+    check(lib.sd_bd_strict_j_counts(M.tensor.data_ptr(), M.T, M.n, M.st, M.sn, tp, m, J,
+                                    out.data_ptr(), ws.data_ptr(), wsb, _stream_ptr(dev)))
+    return out.cpu().numpy()
+
+
+def _points_dev(P, ndim, device):
+    t = torch()
+    dev = _device(device)
+    if isinstance(P, t.Tensor):
+        Pd = P.to(dev, t.float64).contiguous()
+    else:
+        A = np.ascontiguousarray(np.asarray(P, dtype=np.float64))
+        Pd = t.from_numpy(A).to(dev)
+    if Pd.dim() != ndim:
+        raise ValueError(f"expected a {ndim}-D array")
+    return Pd, dev
+
+
+def l1_depth(P, targets=None, device=None):
+    t = torch()
+    lib = _native.require_device()
+    Pd, dev = _points_dev(P, 2, device)
+    n, d = Pd.shape
+    td, m, tp = _targets_dev(targets, n, dev)
+    out = t.empty(m, dtype=t.float64, device=dev)
+    check(lib.sd_l1_depth(Pd.data_ptr(), n, d, tp, m, out.data_ptr(), _stream_ptr(dev)))
+    return out.cpu().numpy()
+
+
+def pointcloud_simplex_counts(P, targets=None, tol=1e-7, samples=None, seed=0, device=None):
+    t = torch()
+    lib = _native.require_device()
+    Pd, dev = _points_dev(P, 2, device)
+    n, d = Pd.shape
+    td, m, tp = _targets_dev(targets, n, dev)
+    out = t.empty(m, dtype=t.int64, device=dev)
+    if samples is None:
+        check(lib.sd_pointcloud_simplex_counts(Pd.data_ptr(), n, d, tp, m, tol, out.data_ptr(), _stream_ptr(dev)))
+    else:
+        check(lib.sd_pointcloud_simplex_sampled(Pd.data_ptr(), n, d, tp, m, tol, int(samples), int(seed),
+                                                out.data_ptr(), _stream_ptr(dev)))
+    return out.cpu().numpy()
+
+
+def multi_simplex_counts(P, targets=None, relax=True, tol=1e-7, samples=None, seed=0, device=None):
+    """P: (n, T, d) curves."""
+    t = torch()
+    lib = _native.require_device()
+    Pd, dev = _points_dev(P, 3, device)
+    n, T, d = Pd.shape
+    td, m, tp = _targets_dev(targets, n, dev)
+    out = t.empty(m, dtype=t.int64, device=dev)
+    if samples is None:
+        check(lib.sd_multi_simplex_counts(Pd.data_ptr(), n, T, d, tp, m, int(bool(relax)), tol,
+                                          out.data_ptr(), _stream_ptr(dev)))
+    else:
+        check(lib.sd_multi_simplex_sampled(Pd.data_ptr(), n, T, d, tp, m, int(bool(relax)), tol, int(samples),
+                                           int(seed), out.data_ptr(), _stream_ptr(dev)))
+    return out.cpu().numpy()
