@@ -61,11 +61,7 @@ def main():
     rng = np.random.default_rng(1234 + rank)
     X_host = rng.normal(size=(T, n_loc)).cumsum(axis=0)
     X_loc = torch.from_numpy(X_host).to(dev)                       # [T, n_loc] time-major, resident in HBM
-    if N > 1:
-        gathered = torch.empty((N, T, n_loc), dtype=torch.float64, device=dev)
-        X_all = torch.empty((T, n), dtype=torch.float64, device=dev)
-    else:
-        X_all = X_loc
+    X_all = X_loc
     targets = torch.arange(rank * n_loc, (rank + 1) * n_loc, dtype=torch.int64, device=dev)
     out = torch.empty((n_loc, J - 1), dtype=torch.int64, device=dev)
     algo = ALGOS[args.algo]
@@ -73,13 +69,16 @@ def main():
     ws = torch.empty(int(wsb), dtype=torch.uint8, device=dev)
     stream = torch.cuda.current_stream(dev)
 
+    from statdepth_amd.distributed import sharded_mbd_counts
+    sizes = [n_loc] * N
+
     def step():
         if N > 1:
-            # exchange step: ring all-gather of curve blocks over xGMI, then lay rows out contiguously
-            dist.all_gather_into_tensor(gathered, X_loc)
-            X_all.view(T, N, n_loc).copy_(gathered.permute(1, 0, 2))
-        check(lib.sd_mbd_counts(X_all.data_ptr(), T, n, n, 1, targets.data_ptr(), n_loc, J, algo,
-                                out.data_ptr(), ws.data_ptr(), wsb, stream.cuda_stream))
+            # product multi-GPU path: RCCL all-gather of the curve blocks, then the local targets' totals
+            out.copy_(sharded_mbd_counts(X_loc, J=J, algo=args.algo, sizes=sizes))
+        else:
+            check(lib.sd_mbd_counts(X_all.data_ptr(), T, n, n, 1, targets.data_ptr(), n_loc, J, algo,
+                                    out.data_ptr(), ws.data_ptr(), wsb, stream.cuda_stream))
 
     def barrier():
         if N > 1:

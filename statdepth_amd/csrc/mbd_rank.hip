@@ -24,6 +24,8 @@
 //
 // Replaces the same reference loops as mbd_pairwise.hip (_functional.py:246-251,
 // _containment.py:75-77); results are bit-identical to it and to the oracle.
+#include <stdlib.h>
+
 #include "sd_common.h"
 
 namespace sd {
@@ -33,7 +35,7 @@ constexpr int RK_MAXG = 1024;   // max persistent workgroups (partial-sum rows)
 template <int NT, int E>
 struct RankCfg {
     static constexpr int N = NT * E;
-    static constexpr int LE = (E == 1) ? 0 : (E == 2) ? 1 : (E == 4) ? 2 : (E == 8) ? 3 : 4;
+    static constexpr int LE = (E == 1) ? 0 : (E == 2) ? 1 : (E == 4) ? 2 : (E == 8) ? 3 : (E == 16) ? 4 : 5;
     static constexpr int LT = (NT == 256) ? 8 : (NT == 512) ? 9 : 10;
     static constexpr int LN = LE + LT;
     static constexpr int SLOTS = N + (N >> LE);       // padded: one slot per E keys
@@ -43,10 +45,19 @@ struct RankCfg {
 template <int LE>
 __device__ __forceinline__ int phys(int p) { return p + (p >> LE); }
 
-// position of (thread t, register r) when registers hold position bits [B, B+LE)
+// Position of (thread t, register r) when registers hold position bits [B, B+LE):
+//   p = ((t >> B) << (B+LE)) | (r << B) | (t & (2^B - 1)).
+// The bit fields are disjoint, so the padded LDS slot splits into a per-thread base and a
+// per-register constant: phys(p) = lds_base<B>(t) + lds_off<B>(r) -- one address VGPR per layout,
+// the rest folds into the ds_read/ds_write immediate offsets.
 template <int B, int LE>
-__device__ __forceinline__ int pos_of(int t, int r) {
-    return ((t >> B) << (B + LE)) | (r << B) | (t & ((1 << B) - 1));
+__device__ __forceinline__ int lds_base(int t) {
+    int u = ((t >> B) << (B + LE)) | (t & ((1 << B) - 1));
+    return u + (u >> LE);
+}
+template <int B, int LE>
+__device__ __forceinline__ constexpr int lds_off(int r) {
+    return (r << B) + ((r << B) >> LE);
 }
 
 __device__ __forceinline__ void cmpx(double &a, double &b) {
@@ -74,8 +85,9 @@ struct RankSorter {
     template <int BF, int BT>
     static __device__ __forceinline__ void transpose(double (&k)[E], double *S, int t) {
         constexpr bool global = (BF > 6) || (BT > 6);
+        double *Sw = S + lds_base<BF, LE>(t);
 #pragma unroll
-        for (int r = 0; r < E; ++r) S[phys<LE>(pos_of<BF, LE>(t, r))] = k[r];
+        for (int r = 0; r < E; ++r) Sw[lds_off<BF, LE>(r)] = k[r];
         if constexpr (global) {
             __syncthreads();
         } else {
@@ -83,8 +95,9 @@ struct RankSorter {
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
+        const double *Sr = S + lds_base<BT, LE>(t);
 #pragma unroll
-        for (int r = 0; r < E; ++r) k[r] = S[phys<LE>(pos_of<BT, LE>(t, r))];
+        for (int r = 0; r < E; ++r) k[r] = Sr[lds_off<BT, LE>(r)];
     }
 
     // levels HI..LO (position bits) with register window at B
@@ -127,7 +140,8 @@ struct RankSorter {
 
 // grid = G persistent workgroups; workgroup g owns timepoints g, g+G, ...
 // partial[(g*(J-1) + j)*n + i] = sum over its timepoints of the band counts of curve i
-template <int NT, int E, int J>
+// PH: debug ablation mask (1 = sort, 2 = search); production launches use PH = 3
+template <int NT, int E, int J, int PH = 3>
 __global__ __launch_bounds__(NT) void mbd_rank_kernel(const double *__restrict__ Y, i64 T, i64 n,
                                                       u64 *__restrict__ partial) {
     using C = RankCfg<NT, E>;
@@ -158,27 +172,40 @@ __global__ __launch_bounds__(NT) void mbd_rank_kernel(const double *__restrict__
         }
         __syncthreads();                       // s_nnan zeroed; previous row's searches finished
         if (mynan) atomicAdd(&s_nnan, mynan);
-        RankSorter<NT, E>::sort(k, Sm, t);
+        if constexpr (PH & 1) RankSorter<NT, E>::sort(k, Sm, t);
+        {
+            double *Sw = Sm + lds_base<0, LE>(t);
 #pragma unroll
-        for (int r = 0; r < E; ++r) Sm[phys<LE>(t * E + r)] = k[r];
+            for (int r = 0; r < E; ++r) Sw[lds_off<0, LE>(r)] = k[r];
+        }
         __syncthreads();
         const u32 nnan = s_nnan;
         // look every own curve up in the sorted row
 #pragma unroll
         for (int e = 0; e < E; ++e) {
+            if ((e & 3) == 0) __builtin_amdgcn_sched_barrier(0);   // keep at most 4 searches in flight (VGPRs)
             i64 i = (i64)t + (i64)e * NT;
-            if (i < n) {
+            if ((PH & 2) && i < n) {
                 double x = row[i];
                 if (x == x) {
-                    int lo = 0, hi = 0;
+                    // lower bound by a fixed-depth descent; x itself is in the row, so Sm[lo] == x afterwards
+                    int lo = 0;
 #pragma unroll
                     for (int s = N >> 1; s >= 1; s >>= 1) {
                         double a = Sm[phys<LE>(lo + s - 1)];
-                        double b = Sm[phys<LE>(hi + s - 1)];
                         lo += (a < x) ? s : 0;
-                        hi += (b <= x) ? s : 0;
                     }
-                    hi += (Sm[phys<LE>(hi)] <= x) ? 1 : 0;
+                    // upper bound: one probe settles it unless x is tied with its successor
+                    int hi = lo + 1;
+                    if (hi < N && Sm[phys<LE>(hi)] <= x) {
+                        hi = 0;
+#pragma unroll
+                        for (int s = N >> 1; s >= 1; s >>= 1) {
+                            double b = Sm[phys<LE>(hi + s - 1)];
+                            hi += (b <= x) ? s : 0;
+                        }
+                        hi += (Sm[phys<LE>(hi)] <= x) ? 1 : 0;
+                    }
                     u32 B = (u32)lo;
                     u32 A = (x == INF) ? 0u : (u32)(N - hi) - npad - nnan;
                     band_counts_add<J>(A, B, nnan, (u64)(n - 1), acc[e]);
@@ -197,16 +224,27 @@ __global__ __launch_bounds__(NT) void mbd_rank_kernel(const double *__restrict__
 }
 
 // out[q*(J-1)+j] = sum_g partial[g][j][targets[q]]
-__global__ __launch_bounds__(256) void rank_reduce_kernel(const u64 *__restrict__ partial, int G, i64 n, int jc,
-                                                          const i64 *__restrict__ targets, i64 m,
-                                                          u64 *__restrict__ out) {
-    i64 q = (i64)blockIdx.x * 256 + threadIdx.x;
-    if (q >= m) return;
-    i64 i = targets ? targets[q] : q;
+// block = 64 targets x 16 slices of g; LDS tree over the slices
+__global__ __launch_bounds__(1024) void rank_reduce_kernel(const u64 *__restrict__ partial, int G, i64 n, int jc,
+                                                           const i64 *__restrict__ targets, i64 m,
+                                                           u64 *__restrict__ out) {
+    __shared__ u64 red[16][64];
+    int x = threadIdx.x & 63, y = threadIdx.x >> 6;
+    i64 q = (i64)blockIdx.x * 64 + x;
+    i64 i = (q < m) ? (targets ? targets[q] : q) : 0;
     for (int j = 0; j < jc; ++j) {
         u64 s = 0;
-        for (int g = 0; g < G; ++g) s += partial[((size_t)g * jc + j) * n + i];
-        out[q * jc + j] = s;
+        if (q < m)
+            for (int g = y; g < G; g += 16) s += partial[((size_t)g * jc + j) * n + i];
+        red[y][x] = s;
+        __syncthreads();
+        if (y == 0 && q < m) {
+            u64 tot = 0;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) tot += red[k][x];
+            out[q * jc + j] = tot;
+        }
+        __syncthreads();
     }
 }
 
@@ -232,10 +270,10 @@ size_t mbd_rank_workspace_bytes(i64 T, i64 n, int J) {
     return (size_t)g * (J - 1) * n * 8;
 }
 
-template <int NT, int E, int J>
+template <int NT, int E, int J, int PH = 3>
 static int launch_rank_cfg(const double *Y, i64 T, i64 n, u64 *partial, int G, hipStream_t s) {
     using C = RankCfg<NT, E>;
-    auto kern = mbd_rank_kernel<NT, E, J>;
+    auto kern = mbd_rank_kernel<NT, E, J, PH>;
     SD_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES));
     hipLaunchKernelGGL(kern, dim3(G), dim3(NT), C::LDS_BYTES, s, Y, T, n, partial);
     SD_HIP(hipGetLastError());
@@ -248,6 +286,14 @@ static int launch_rank_j(const double *Y, i64 T, i64 n, u64 *partial, int G, hip
     if (n <= 2048) return launch_rank_cfg<256, 8, J>(Y, T, n, partial, G, s);
     if (n <= 4096) return launch_rank_cfg<1024, 4, J>(Y, T, n, partial, G, s);
     if (n <= 8192) return launch_rank_cfg<1024, 8, J>(Y, T, n, partial, G, s);
+    // debug knobs (timing experiments only): SD_RANK_CFG=2 -> 512x32, SD_RANK_PH = ablation mask
+    const char *cfg = getenv("SD_RANK_CFG");
+    const char *ph = getenv("SD_RANK_PH");
+    int phv = ph ? atoi(ph) : 3;
+    if (J == 2 && phv == 1) return launch_rank_cfg<512, 32, 2, 1>(Y, T, n, partial, G, s);
+    if (J == 2 && phv == 2) return launch_rank_cfg<512, 32, 2, 2>(Y, T, n, partial, G, s);
+    if (J == 2 && phv == 0) return launch_rank_cfg<512, 32, 2, 0>(Y, T, n, partial, G, s);
+    if (cfg && atoi(cfg) == 2) return launch_rank_cfg<512, 32, J>(Y, T, n, partial, G, s);
     return launch_rank_cfg<1024, 16, J>(Y, T, n, partial, G, s);
 }
 
@@ -260,7 +306,7 @@ int launch_mbd_rank(const double *Y, i64 T, i64 n, const i64 *targets, i64 m, in
     u64 *partial = (u64 *)ws;
     int rc = (J == 2) ? launch_rank_j<2>(Y, T, n, partial, G, s) : launch_rank_j<3>(Y, T, n, partial, G, s);
     if (rc) return rc;
-    hipLaunchKernelGGL(rank_reduce_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s, partial, G, n, J - 1,
+    hipLaunchKernelGGL(rank_reduce_kernel, dim3((unsigned)((m + 63) / 64)), dim3(1024), 0, s, partial, G, n, J - 1,
                        targets, m, out);
     SD_HIP(hipGetLastError());
     return SD_OK;

@@ -1,0 +1,80 @@
+"""world_size=2 (and 3, ragged) gloo tests of the target-sharded path on CPU.
+
+The exchange logic (ragged all-gather of curve blocks, target slices, result gather,
+global normaliser) is what is under test; the compute hook is the oracle here because
+there is no GPU in this container -- on a GPU box the default hook is the HIP engine
+(tests/test_hip_parity.py covers that kernel).
+"""
+import os
+import socket
+
+import numpy as np
+import pandas as pd
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _oracle_compute(X_all, targets, J, algo):
+    import oracle
+    return oracle.mbd_counts(X_all.cpu().numpy(), targets, J)
+
+
+def _worker(rank, world, port, splits, J, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from statdepth_amd.distributed import sharded_functional_depth, sharded_mbd_counts
+        rng = np.random.default_rng(42)
+        T, n = 23, splits[-1]
+        X = np.round(rng.normal(size=(T, n)).cumsum(axis=0), 1)
+        lo, hi = splits[rank], splits[rank + 1]
+        X_loc = torch.from_numpy(np.ascontiguousarray(X[:, lo:hi]))
+        loc = sharded_mbd_counts(X_loc, J=J, _compute=_oracle_compute)
+        full = sharded_mbd_counts(X_loc, J=J, gather_result=True, _compute=_oracle_compute)
+        df = pd.DataFrame(X[:, lo:hi], columns=[f"c{i}" for i in range(lo, hi)])
+        ser = sharded_functional_depth(df, J=J, relax=True, _compute=_oracle_compute)
+        q.put((rank, loc.numpy(), full.numpy(), ser))
+    except Exception as e:   # surface the failure instead of letting the parent time out
+        q.put((rank, repr(e), None, None))
+        raise
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("splits,J", [([0, 20, 40], 2), ([0, 7, 30], 3), ([0, 5, 6, 31], 2)])
+def test_sharded_equals_single(splits, J):
+    import oracle
+    world = len(splits) - 1
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, splits, J, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    rng = np.random.default_rng(42)
+    T, n = 23, splits[-1]
+    X = np.round(rng.normal(size=(T, n)).cumsum(axis=0), 1)
+    want = oracle.mbd_counts(X, None, J)
+    wantd = oracle.univariate_depths(X, None, J=J, relax=True)
+    for rank, loc, full, ser in res:
+        assert not isinstance(loc, str), loc
+        lo, hi = splits[rank], splits[rank + 1]
+        assert (loc == want[lo:hi]).all()            # integer totals do not depend on the sharding
+        assert (full == want).all()
+        assert list(ser.index) == [f"c{i}" for i in range(lo, hi)]
+        assert np.max(np.abs(ser.to_numpy() - wantd[lo:hi])) <= 1e-12

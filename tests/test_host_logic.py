@@ -1,0 +1,166 @@
+"""CPU-side tests: the C-ABI library loads and exports what include/statdepth_hip.h declares,
+the host mirror of the reference's API validates arguments the same way, result objects
+behave like the reference's, and the product fails loudly without a GPU (no CPU fallback)."""
+import os
+import re
+
+import numpy as np
+import pandas as pd
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def built():
+    import __graft_entry__ as g
+    g.build()
+    from statdepth_amd import _native
+    return _native
+
+
+def _declared_symbols():
+    src = open(os.path.join(ROOT, "include", "statdepth_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(sd_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol(built):
+    import ctypes
+    lib = ctypes.CDLL(built.LIB_PATH)
+    declared = _declared_symbols()
+    assert len(declared) >= 20
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in statdepth_hip.h but not exported"
+    # and the Python binding table covers exactly the header
+    assert sorted(built.SIGNATURES) == declared
+
+
+def test_abi_version_and_error_string(built):
+    lib = built.load()
+    assert lib.sd_abi_version() == 1
+    # argument validation happens before any device work: callable without a GPU
+    rc = lib.sd_mbd_counts(None, 10, 10, 10, 1, None, 10, 2, 0, None, None, 0, None)
+    assert rc == built.SD_ERR_INVALID
+    assert b"null" in lib.sd_last_error()
+    rc = lib.sd_mbd_counts(1, 10, 10, 3, 7, None, 10, 2, 0, 1, None, 0, None)
+    assert rc == built.SD_ERR_INVALID and b"time-major" in lib.sd_last_error()
+    rc = lib.sd_mbd_counts(1, 1000, 100000, 100000, 1, None, 100000, 4, 0, 1, None, 0, None)
+    assert rc == built.SD_ERR_OVERFLOW
+    rc = lib.sd_bd_strict_j_counts(1, 10, 10, 10, 1, None, 10, 5, 1, None, 0, None)
+    assert rc == built.SD_ERR_UNSUPPORTED
+    rc = lib.sd_pointcloud_simplex_counts(1, 10, 9, None, 10, 1e-7, 1, None)
+    assert rc == built.SD_ERR_UNSUPPORTED
+    assert lib.sd_mbd_workspace_bytes(1000, 10000, 10000, 1, 10000, 2, 0) >= 1000 * 4
+
+
+def test_no_cpu_fallback(built):
+    """Without a device the product raises; it never routes to the oracle or any CPU path."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from statdepth_amd import FunctionalDepth, PointcloudDepth
+    df = pd.DataFrame(np.random.default_rng(0).normal(size=(6, 5)))
+    with pytest.raises(RuntimeError, match="no HIP device"):
+        FunctionalDepth([df], relax=True)
+    with pytest.raises(RuntimeError, match="no HIP device"):
+        FunctionalDepth([df], relax=False)
+    with pytest.raises(RuntimeError, match="no HIP device"):
+        PointcloudDepth(df.iloc[:, :2], containment="l1")
+    src = ""
+    for dp, _, fns in os.walk(os.path.join(ROOT, "statdepth_amd")):
+        for fn in fns:
+            if fn.endswith(".py"):
+                src += open(os.path.join(dp, fn)).read()
+    assert "import oracle" not in src and "from oracle" not in src
+
+
+def test_handle_depth_errors_mirror_reference():
+    """Same checks, same order, same exception types as _helper.py:59-107."""
+    from statdepth_amd import DepthDegeneracy, FunctionalDepth
+    df = pd.DataFrame(np.arange(20.0).reshape(5, 4))
+    with pytest.raises(ValueError, match="passed as a list"):
+        FunctionalDepth(df)
+    with pytest.raises(ValueError, match="J must be an integer"):
+        FunctionalDepth([df], J=2.0)
+    with pytest.raises(ValueError, match="str or Callable"):
+        FunctionalDepth([df], containment=3)
+    with pytest.raises(ValueError, match="deep_check"):
+        FunctionalDepth([df], deep_check=1)
+    with pytest.raises(ValueError, match="relax must be"):
+        FunctionalDepth([df], relax=1)
+    with pytest.raises(ValueError, match="greater than or equal to 2"):
+        FunctionalDepth([df], J=1)
+    with pytest.raises(ValueError, match="No data"):
+        FunctionalDepth([])
+    with pytest.raises(ValueError, match="less than the number of observations"):
+        FunctionalDepth([df], J=5)          # J compared with the number of ROWS (timepoints), _helper.py:83
+    with pytest.raises(ValueError, match="invalid for multivariate"):
+        FunctionalDepth([df, df, df], containment="r2")
+    with pytest.raises(DepthDegeneracy):
+        FunctionalDepth([df, df, df], containment="simplex")     # needs >= d + 2 = 6 functions
+    with pytest.raises(ValueError, match="is invalid"):
+        FunctionalDepth([df], containment="nonsense")
+    with pytest.raises(ValueError, match="incorrect number of parameters"):
+        FunctionalDepth([df], containment=lambda a, b: 0.0)
+    with pytest.raises(NotImplementedError):
+        FunctionalDepth([df], containment="r2_enum")
+    obj = pd.DataFrame({"a": ["x", "y", "z"], "b": [1, 2, 3]})
+    with pytest.raises(ValueError, match="numeric dtypes"):
+        FunctionalDepth([obj], deep_check=True)
+    from statdepth_amd import PointcloudDepth
+    with pytest.raises(ValueError, match="not a valid containment"):
+        PointcloudDepth(df, containment="nonsense")
+    with pytest.raises(DepthDegeneracy, match="Block size"):
+        FunctionalDepth([df], K=9)
+
+
+def test_custom_containment_callable_runs_on_host():
+    """The plug-in protocol (docs/index.md:124-148) is host logic: one call per subset, keyword arguments."""
+    from statdepth_amd import FunctionalDepth
+    df = pd.DataFrame({"a": [1.0, 2, 3], "b": [2.0, 3, 4], "c": [0.0, 5, 1], "d": [1.5, 2.5, 3.5]})
+    calls = []
+
+    def inside(data, curve, relax):
+        calls.append((tuple(data.columns), curve.name, relax))
+        ok = ((data.min(axis=1) <= curve) & (curve <= data.max(axis=1))).sum()
+        return ok / len(curve) if relax else ok // len(curve)
+
+    got = FunctionalDepth([df], containment=inside, relax=True)
+    assert len(calls) == 4 * 3 and calls[0][2] is True
+    # same numbers as the built-in definition (checked against the oracle, no GPU involved)
+    import oracle
+    want = oracle.univariate_depths(df.to_numpy(), None, J=2, relax=True)
+    assert np.allclose(got.to_numpy(), want, atol=1e-12)
+    assert list(got.index) == list(df.columns)
+
+
+def test_result_objects_behave_like_reference():
+    from statdepth_amd.depth.depth import _FunctionalDepthUnivariate, _PointwiseDepth
+    df = pd.DataFrame(np.arange(12.0).reshape(3, 4), columns=list("wxyz"))
+    depths = pd.Series([0.2, 0.4, 0.1, 0.3], index=list("wxyz"))
+    r = _FunctionalDepthUnivariate(df=df, depths=depths)
+    assert isinstance(r, pd.Series) and r.get_data() is df
+    assert list(r.ordered().index) == ["x", "z", "w", "y"]
+    assert list(r.deepest(n=2).index) == ["x", "z"] and r.median().index[0] == "x"
+    assert list(r.outlying(n=2).index) == ["w", "y"] and r.outlying().index[0] == "y"
+    assert list(r.sorted().index) == ["x", "z", "w", "y"]
+    assert list(r.quartile().index) == ["y", "w"]            # lower half, `ratio` ignored like the reference
+    assert r.depths() is depths and r.get_depths() is depths
+    assert list(r.drop_outlying_data(n=1).columns) == ["w", "x", "z"]
+    assert list(r.get_deepest_data(n=2).columns) == ["x", "z"]
+    assert list(r.get_outlying_data(n=1).columns) == ["y"]
+    pts = pd.DataFrame(np.arange(8.0).reshape(4, 2), index=list("abcd"))
+    p = _PointwiseDepth(df=pts, depths=pd.Series([0.1, 0.5, 0.3, 0.2], index=list("abcd")))
+    assert list(p.drop_outlying_data(n=1).index) == ["b", "c", "d"]
+    assert list(p.get_deepest_data(n=2).index) == ["b", "c"]
+
+
+def test_device_matrix_accepts_both_pandas_layouts():
+    """Ingest keeps the frame's memory order: strides are what the C ABI receives."""
+    a = np.arange(12.0).reshape(3, 4)
+    c = pd.DataFrame(a)                                   # C-contiguous T x n
+    f = pd.DataFrame({k: a[:, k] for k in range(4)})      # column-built
+    xc = c.to_numpy(dtype=np.float64, copy=False)
+    xf = f.to_numpy(dtype=np.float64, copy=False)
+    assert xc.flags.c_contiguous and (xc == xf).all()
