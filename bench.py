@@ -121,7 +121,7 @@ def main():
             "pair_timepoints_per_s": value * T,
             "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK, "traffic": None,
-                         "kernel": "mbd_rank_kernel" if used == "rank" else "mbd_pairwise_kernel",
+                         "kernel": "mbd_rank2_kernel" if used == "rank" else "mbd_pairwise_kernel",
                          "kernel_ms": dev_ms, "algorithmic_bytes": bytes_alg},
             "checksum": result_sum,
         }

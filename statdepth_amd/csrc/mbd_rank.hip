@@ -61,8 +61,11 @@ __device__ __forceinline__ constexpr int lds_off(int r) {
 }
 
 __device__ __forceinline__ void cmpx(double &a, double &b) {
-    double lo = __builtin_fmin(a, b);
-    double hi = __builtin_fmax(a, b);
+    // exactly two instructions: the builtin fmin/fmax add a canonicalising v_max_f64 x,x,x per operand
+    // after every LDS load (keys are never NaN here, so no quieting is needed)
+    double lo, hi;
+    asm("v_min_f64 %0, %1, %2" : "=v"(lo) : "v"(a), "v"(b));
+    asm("v_max_f64 %0, %1, %2" : "=v"(hi) : "v"(a), "v"(b));
     a = lo;
     b = hi;
 }
@@ -73,7 +76,7 @@ __device__ __forceinline__ double flip_sign(double v, unsigned m) {   // m = 0 o
     return __longlong_as_double(u);
 }
 
-template <int NT, int E>
+template <int NT, int E, int SK = 0>
 struct RankSorter {
     using C = RankCfg<NT, E>;
     static constexpr int LE = C::LE;
@@ -116,8 +119,8 @@ struct RankSorter {
     static __device__ __forceinline__ void windows(double (&k)[E], double *Sm, int t) {
         constexpr int B = wb(S, K);
         constexpr int HI = (K == 0) ? S - 1 : BPREV - 1;
-        if constexpr (B != BPREV) transpose<BPREV, B>(k, Sm, t);
-        levels<B, HI, B>(k);
+        if constexpr (B != BPREV && !(SK & 2)) transpose<BPREV, B>(k, Sm, t);
+        if constexpr (!(SK & 1)) levels<B, HI, B>(k);
         if constexpr (B > 0) windows<S, K + 1, B>(k, Sm, t);
     }
 
@@ -172,7 +175,7 @@ __global__ __launch_bounds__(NT) void mbd_rank_kernel(const double *__restrict__
         }
         __syncthreads();                       // s_nnan zeroed; previous row's searches finished
         if (mynan) atomicAdd(&s_nnan, mynan);
-        if constexpr (PH & 1) RankSorter<NT, E>::sort(k, Sm, t);
+        if constexpr (PH & 1) RankSorter<NT, E, (PH >> 2)>::sort(k, Sm, t);
         {
             double *Sw = Sm + lds_base<0, LE>(t);
 #pragma unroll
@@ -290,16 +293,33 @@ static int launch_rank_j(const double *Y, i64 T, i64 n, u64 *partial, int G, hip
     const char *cfg = getenv("SD_RANK_CFG");
     const char *ph = getenv("SD_RANK_PH");
     int phv = ph ? atoi(ph) : 3;
-    if (J == 2 && phv == 1) return launch_rank_cfg<512, 32, 2, 1>(Y, T, n, partial, G, s);
-    if (J == 2 && phv == 2) return launch_rank_cfg<512, 32, 2, 2>(Y, T, n, partial, G, s);
-    if (J == 2 && phv == 0) return launch_rank_cfg<512, 32, 2, 0>(Y, T, n, partial, G, s);
+    if (J == 2 && phv == 1) return launch_rank_cfg<1024, 16, 2, 1>(Y, T, n, partial, G, s);
+    if (J == 2 && phv == 2) return launch_rank_cfg<1024, 16, 2, 2>(Y, T, n, partial, G, s);
+    if (J == 2 && phv == 0) return launch_rank_cfg<1024, 16, 2, 0>(Y, T, n, partial, G, s);
+    if (J == 2 && phv == 5) return launch_rank_cfg<1024, 16, 2, 5>(Y, T, n, partial, G, s);    // sort without CE
+    if (J == 2 && phv == 9) return launch_rank_cfg<1024, 16, 2, 9>(Y, T, n, partial, G, s);    // sort without transposes
     if (cfg && atoi(cfg) == 2) return launch_rank_cfg<512, 32, J>(Y, T, n, partial, G, s);
     return launch_rank_cfg<1024, 16, J>(Y, T, n, partial, G, s);
 }
 
+void launch_rank_reduce(const u64 *partial, int G, i64 n, int jc, const i64 *targets, i64 m, u64 *out, hipStream_t s) {
+    hipLaunchKernelGGL(rank_reduce_kernel, dim3((unsigned)((m + 63) / 64)), dim3(1024), 0, s, partial, G, n, jc,
+                       targets, m, out);
+}
+
+int rank_grid_for(i64 T) { return rank_grid(T); }
+
+int launch_mbd_rank2(const double *Y, i64 T, i64 n, const i64 *targets, i64 m, int J,
+                     u64 *out, void *ws, size_t ws_bytes, hipStream_t s);
+
 int launch_mbd_rank(const double *Y, i64 T, i64 n, const i64 *targets, i64 m, int J,
                     u64 *out, void *ws, size_t ws_bytes, hipStream_t s) {
     if (!mbd_rank_supported(T, n, J)) return fail(SD_ERR_UNSUPPORTED, "rank kernel covers 2 <= n <= 16384, J in {2,3}");
+    {
+        // SD_RANK_IMPL=1 selects the first-generation kernel (full keys + search) for A/B timing and cross-checks
+        const char *impl = getenv("SD_RANK_IMPL");
+        if (!(impl && atoi(impl) == 1)) return launch_mbd_rank2(Y, T, n, targets, m, J, out, ws, ws_bytes, s);
+    }
     int G = rank_grid(T);
     size_t need = (size_t)G * (J - 1) * n * 8;
     if (!ws || ws_bytes < need) return fail(SD_ERR_WORKSPACE, "rank workspace too small");
