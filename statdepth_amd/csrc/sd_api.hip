@@ -133,6 +133,8 @@ static int resolve_mbd_algo(int algo, i64 T, i64 n, i64 m, int J) {
     if (algo == SD_MBD_PAIRWISE || algo == SD_MBD_RANK) return algo;
     // rank costs ~n log n per timepoint whatever m is; pairwise costs m*n.
     if (mbd_rank_supported(T, n, J) && m >= 32) return SD_MBD_RANK;
+    // chunked rank: work ~ (n/C) sorts + (n/C)^2 searches per row whatever m is; pairwise costs m*n
+    if (mbd_rank_big_supported(T, n, J) && m >= 2048) return SD_MBD_RANK;
     return SD_MBD_PAIRWISE;
 }
 
@@ -142,7 +144,8 @@ size_t sd_mbd_workspace_bytes(int64_t T, int64_t n, int64_t st, int64_t sn, int6
     if (!is_time_major_dense(n, st, sn)) b += align_up((size_t)T * n * 8, 256);
     b += align_up((size_t)T * 4, 256);   // nan_cnt
     int a = resolve_mbd_algo(algo, T, n, m, J);
-    if (a == SD_MBD_RANK || algo == SD_MBD_AUTO) b += align_up(mbd_rank_workspace_bytes(T, n, J), 256) + 256;
+    if (a == SD_MBD_RANK || algo == SD_MBD_AUTO)
+        b += align_up(mbd_rank_workspace_bytes(T, n, J) + mbd_rank_big_workspace_bytes(T, n, J), 256) + 256;
     return b + 1024;
 }
 
@@ -165,6 +168,12 @@ int sd_mbd_counts(const double *X, int64_t T, int64_t n, int64_t st, int64_t sn,
         Y = Yw;
     }
     int a = resolve_mbd_algo(algo, T, n, m, J);
+    if (a == SD_MBD_RANK && mbd_rank_big_supported(T, n, J)) {
+        size_t need = mbd_rank_big_workspace_bytes(T, n, J);
+        void *rws = cv.take(need);
+        if (!rws) return fail(SD_ERR_WORKSPACE, "workspace too small for the chunked rank kernel");
+        return launch_mbd_rank_big(Y, T, n, targets, m, J, (u64 *)out, rws, need, s);
+    }
     if (a == SD_MBD_RANK) {
         if (!mbd_rank_supported(T, n, J))
             return fail(SD_ERR_UNSUPPORTED, "rank kernel does not cover T=%lld n=%lld J=%d", (long long)T, (long long)n, J);

@@ -55,6 +55,11 @@ size_t mbd_rank_workspace_bytes(i64 T, i64 n, int J);
 bool mbd_rank_supported(i64 T, i64 n, int J);
 int launch_mbd_rank(const double *Y, i64 T, i64 n, const i64 *targets, i64 m, int J,
                     u64 *out, void *ws, size_t ws_bytes, hipStream_t s);
+// K1+K2 rank formulation for n > 16384 (chunked)
+bool mbd_rank_big_supported(i64 T, i64 n, int J);
+size_t mbd_rank_big_workspace_bytes(i64 T, i64 n, int J);
+int launch_mbd_rank_big(const double *Y, i64 T, i64 n, const i64 *targets, i64 m, int J,
+                        u64 *out, void *ws, size_t ws_bytes, hipStream_t s);
 // K3 strict
 size_t bd_strict_workspace_bytes(i64 T, i64 n, i64 m, int J);
 int launch_bd_strict(const double *Y, i64 T, i64 n, const i64 *targets, i64 m, int J,

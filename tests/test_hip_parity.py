@@ -98,7 +98,8 @@ def _cases():
     out = []
     for (T, n, kind) in [(1, 2, "normal"), (3, 5, "ints"), (17, 33, "normal"), (64, 64, "ints"),
                          (65, 257, "walk"), (100, 50, "normal"), (37, 1023, "ints"), (9, 1025, "walk"),
-                         (130, 2049, "normal"), (5, 4097, "ints"), (3, 8200, "walk"), (2, 16384, "ints")]:
+                         (130, 2049, "normal"), (5, 4097, "ints"), (3, 8200, "walk"), (2, 16384, "ints"),
+                         (3, 16385, "ints"), (2, 33000, "walk"), (4, 40000, "normal")]:
         if kind == "normal":
             X = rng.normal(size=(T, n))
         elif kind == "ints":
@@ -114,7 +115,7 @@ def _cases():
 def test_mbd_counts_vs_oracle(eng, oracle, X, algo):
     T, n = X.shape
     for J in (2, 3):
-        if n - 1 < J:
+        if n - 1 < J or (n > 20000 and J == 3):
             continue
         want = oracle.mbd_counts(X, None, J)
         assert (eng.mbd_counts(X, None, J, algo=algo) == want).all()
