@@ -36,6 +36,8 @@ def main():
     ap.add_argument("--algo", default="auto", choices=["auto", "pairwise", "rank"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-targets", type=int, default=4096)
+    ap.add_argument("--force-dist", action="store_true",
+                    help="run the torch.distributed path even at world size 1 (exercises RCCL on one GPU)")
     args = ap.parse_args()
 
     import torch
@@ -46,8 +48,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     N = world
     assert args.gpus == N, f"--gpus {args.gpus} but WORLD_SIZE={world}"
@@ -73,7 +79,7 @@ def main():
     sizes = [n_loc] * N
 
     def step():
-        if N > 1:
+        if use_dist:
             # product multi-GPU path: RCCL all-gather of the curve blocks, then the local targets' totals
             out.copy_(sharded_mbd_counts(X_loc, J=J, algo=args.algo, sizes=sizes))
         else:
@@ -81,7 +87,7 @@ def main():
                                     out.data_ptr(), ws.data_ptr(), wsb, stream.cuda_stream))
 
     def barrier():
-        if N > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -97,7 +103,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     dev_ms = ev0.elapsed_time(ev1) / args.steps          # device time per step on the launch stream
-    if N > 1:
+    if use_dist:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -107,7 +113,8 @@ def main():
 
     result_sum = int(out.sum().item())
     if rank == 0:
-        used = "rank" if (args.algo == "rank" or (args.algo == "auto" and n <= 16384 and J <= 3)) else "pairwise"
+        used = "rank" if (args.algo == "rank" or (args.algo == "auto" and J <= 3)) else "pairwise"
+        kern = "mbd_pairwise_kernel" if used == "pairwise" else ("mbd_rank2_kernel" if n <= 16384 else "chunk_search_kernel")
         bytes_alg = 8.0 * T * (n + n_loc) + 8.0 * n_loc * (J - 1)   # per GPU per call
         achieved = bytes_alg / (dev_ms * 1e-3)
         line = {
@@ -121,7 +128,7 @@ def main():
             "pair_timepoints_per_s": value * T,
             "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK, "traffic": None,
-                         "kernel": "mbd_rank2_kernel" if used == "rank" else "mbd_pairwise_kernel",
+                         "kernel": kern,
                          "kernel_ms": dev_ms, "algorithmic_bytes": bytes_alg},
             "checksum": result_sum,
         }
@@ -142,7 +149,7 @@ def main():
                           f"{T} timepoints, {cpu_dt:.2f} s; work is linear in #targets",
             }
         print(json.dumps(line), flush=True)
-    if N > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

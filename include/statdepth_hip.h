@@ -90,6 +90,13 @@ int sd_mbd_counts(const double *X, int64_t T, int64_t n, int64_t st, int64_t sn,
                   const int64_t *targets, int64_t m, int J, int algo,
                   int64_t *out, void *ws, size_t ws_bytes, void *stream);
 
+/* Same totals for a CONTIGUOUS block of targets [target_begin, target_begin + m) -- the form the
+ * target-sharded multi-GPU path uses (rank r owns one block of curves of the gathered set).  Lets the
+ * chunked rank kernel search only the chunks that hold targets. */
+int sd_mbd_counts_range(const double *X, int64_t T, int64_t n, int64_t st, int64_t sn,
+                        int64_t target_begin, int64_t m, int J, int algo,
+                        int64_t *out, void *ws, size_t ws_bytes, void *stream);
+
 /* Finest-granularity form of K1 (tests, diagnostics): AB[(q*T + t)*2 + {0,1}] =
  * (#curves strictly above, #strictly below) target q at t, as uint32. */
 int sd_above_below(const double *X, int64_t T, int64_t n, int64_t st, int64_t sn,

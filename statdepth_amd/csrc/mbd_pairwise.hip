@@ -82,11 +82,11 @@ constexpr int PW_TB = 4;   // timepoints per workgroup
 
 template <int J, bool WRITE_AB>
 __global__ __launch_bounds__(PW_THREADS) void mbd_pairwise_kernel(
-    const double *__restrict__ Y, i64 T, i64 n, const i64 *__restrict__ targets, i64 m,
+    const double *__restrict__ Y, i64 T, i64 n, const i64 *__restrict__ targets, i64 tbegin, i64 m,
     const u32 *__restrict__ nan_cnt, u64 *__restrict__ out, u32 *__restrict__ AB) {
     i64 q = (i64)blockIdx.x * PW_THREADS + threadIdx.x;
     bool valid = q < m;
-    i64 tg = valid ? (targets ? targets[q] : q) : 0;
+    i64 tg = valid ? (targets ? targets[q] : tbegin + q) : 0;
     i64 t0 = (i64)blockIdx.y * PW_TB;
     u64 acc[JMAX - 1];
 #pragma unroll
@@ -130,19 +130,19 @@ __global__ __launch_bounds__(PW_THREADS) void mbd_pairwise_kernel(
     }
 }
 
-int launch_mbd_pairwise(const double *Y, i64 T, i64 n, const i64 *targets, i64 m, int J,
+int launch_mbd_pairwise(const double *Y, i64 T, i64 n, const i64 *targets, i64 tbegin, i64 m, int J,
                         const u32 *nan_cnt, u64 *out, hipStream_t s) {
     SD_HIP(hipMemsetAsync(out, 0, sizeof(u64) * m * (J - 1), s));
     dim3 grid((unsigned)((m + PW_THREADS - 1) / PW_THREADS), (unsigned)((T + PW_TB - 1) / PW_TB));
     SD_DISPATCH_J(J, hipLaunchKernelGGL((mbd_pairwise_kernel<J_, false>), grid, dim3(PW_THREADS), 0, s,
-                                        Y, T, n, targets, m, nan_cnt, out, (u32 *)nullptr));
+                                        Y, T, n, targets, tbegin, m, nan_cnt, out, (u32 *)nullptr));
     SD_HIP(hipGetLastError());
     return SD_OK;
 }
 
 int launch_above_below(const double *Y, i64 T, i64 n, const i64 *targets, i64 m, u32 *AB, hipStream_t s) {
     dim3 grid((unsigned)((m + PW_THREADS - 1) / PW_THREADS), (unsigned)((T + PW_TB - 1) / PW_TB));
-    hipLaunchKernelGGL((mbd_pairwise_kernel<2, true>), grid, dim3(PW_THREADS), 0, s, Y, T, n, targets, m,
+    hipLaunchKernelGGL((mbd_pairwise_kernel<2, true>), grid, dim3(PW_THREADS), 0, s, Y, T, n, targets, (i64)0, m,
                        (const u32 *)nullptr, (u64 *)nullptr, AB);
     SD_HIP(hipGetLastError());
     return SD_OK;

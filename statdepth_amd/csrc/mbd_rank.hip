@@ -229,12 +229,12 @@ __global__ __launch_bounds__(NT) void mbd_rank_kernel(const double *__restrict__
 // out[q*(J-1)+j] = sum_g partial[g][j][targets[q]]
 // block = 64 targets x 16 slices of g; LDS tree over the slices
 __global__ __launch_bounds__(1024) void rank_reduce_kernel(const u64 *__restrict__ partial, int G, i64 n, int jc,
-                                                           const i64 *__restrict__ targets, i64 m,
+                                                           const i64 *__restrict__ targets, i64 tbegin, i64 m,
                                                            u64 *__restrict__ out) {
     __shared__ u64 red[16][64];
     int x = threadIdx.x & 63, y = threadIdx.x >> 6;
     i64 q = (i64)blockIdx.x * 64 + x;
-    i64 i = (q < m) ? (targets ? targets[q] : q) : 0;
+    i64 i = (q < m) ? (targets ? targets[q] : tbegin + q) : 0;
     for (int j = 0; j < jc; ++j) {
         u64 s = 0;
         if (q < m)
@@ -302,23 +302,24 @@ static int launch_rank_j(const double *Y, i64 T, i64 n, u64 *partial, int G, hip
     return launch_rank_cfg<1024, 16, J>(Y, T, n, partial, G, s);
 }
 
-void launch_rank_reduce(const u64 *partial, int G, i64 n, int jc, const i64 *targets, i64 m, u64 *out, hipStream_t s) {
+void launch_rank_reduce(const u64 *partial, int G, i64 n, int jc, const i64 *targets, i64 tbegin, i64 m, u64 *out,
+                        hipStream_t s) {
     hipLaunchKernelGGL(rank_reduce_kernel, dim3((unsigned)((m + 63) / 64)), dim3(1024), 0, s, partial, G, n, jc,
-                       targets, m, out);
+                       targets, tbegin, m, out);
 }
 
 int rank_grid_for(i64 T) { return rank_grid(T); }
 
-int launch_mbd_rank2(const double *Y, i64 T, i64 n, const i64 *targets, i64 m, int J,
+int launch_mbd_rank2(const double *Y, i64 T, i64 n, const i64 *targets, i64 tbegin, i64 m, int J,
                      u64 *out, void *ws, size_t ws_bytes, hipStream_t s);
 
-int launch_mbd_rank(const double *Y, i64 T, i64 n, const i64 *targets, i64 m, int J,
+int launch_mbd_rank(const double *Y, i64 T, i64 n, const i64 *targets, i64 tbegin, i64 m, int J,
                     u64 *out, void *ws, size_t ws_bytes, hipStream_t s) {
     if (!mbd_rank_supported(T, n, J)) return fail(SD_ERR_UNSUPPORTED, "rank kernel covers 2 <= n <= 16384, J in {2,3}");
     {
         // SD_RANK_IMPL=1 selects the first-generation kernel (full keys + search) for A/B timing and cross-checks
         const char *impl = getenv("SD_RANK_IMPL");
-        if (!(impl && atoi(impl) == 1)) return launch_mbd_rank2(Y, T, n, targets, m, J, out, ws, ws_bytes, s);
+        if (!(impl && atoi(impl) == 1)) return launch_mbd_rank2(Y, T, n, targets, tbegin, m, J, out, ws, ws_bytes, s);
     }
     int G = rank_grid(T);
     size_t need = (size_t)G * (J - 1) * n * 8;
@@ -327,7 +328,7 @@ int launch_mbd_rank(const double *Y, i64 T, i64 n, const i64 *targets, i64 m, in
     int rc = (J == 2) ? launch_rank_j<2>(Y, T, n, partial, G, s) : launch_rank_j<3>(Y, T, n, partial, G, s);
     if (rc) return rc;
     hipLaunchKernelGGL(rank_reduce_kernel, dim3((unsigned)((m + 63) / 64)), dim3(1024), 0, s, partial, G, n, J - 1,
-                       targets, m, out);
+                       targets, tbegin, m, out);
     SD_HIP(hipGetLastError());
     return SD_OK;
 }

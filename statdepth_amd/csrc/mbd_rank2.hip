@@ -119,7 +119,8 @@ __global__ __launch_bounds__(NT) void mbd_rank2_kernel(const double *__restrict_
 }
 
 // (reduction kernel shared with mbd_rank.hip)
-void launch_rank_reduce(const u64 *partial, int G, i64 n, int jc, const i64 *targets, i64 m, u64 *out, hipStream_t s);
+void launch_rank_reduce(const u64 *partial, int G, i64 n, int jc, const i64 *targets, i64 tbegin, i64 m, u64 *out,
+                        hipStream_t s);
 int rank_grid_for(i64 T);
 
 template <int NT, int E, int J, int DBG = 0>
@@ -145,7 +146,7 @@ static int launch_rank2_j(const double *Y, i64 T, i64 n, u64 *partial, int G, hi
     return launch_rank2_cfg<1024, 16, J>(Y, T, n, partial, G, s);
 }
 
-int launch_mbd_rank2(const double *Y, i64 T, i64 n, const i64 *targets, i64 m, int J,
+int launch_mbd_rank2(const double *Y, i64 T, i64 n, const i64 *targets, i64 tbegin, i64 m, int J,
                      u64 *out, void *ws, size_t ws_bytes, hipStream_t s) {
     int G = rank_grid_for(T);
     size_t need = (size_t)G * (J - 1) * n * 8;
@@ -153,7 +154,7 @@ int launch_mbd_rank2(const double *Y, i64 T, i64 n, const i64 *targets, i64 m, i
     u64 *partial = (u64 *)ws;
     int rc = (J == 2) ? launch_rank2_j<2>(Y, T, n, partial, G, s) : launch_rank2_j<3>(Y, T, n, partial, G, s);
     if (rc) return rc;
-    launch_rank_reduce(partial, G, n, J - 1, targets, m, out, s);
+    launch_rank_reduce(partial, G, n, J - 1, targets, tbegin, m, out, s);
     SD_HIP(hipGetLastError());
     return SD_OK;
 }

@@ -67,12 +67,14 @@ template <int J>
 __global__ __launch_bounds__(BIG_NT) void chunk_search_kernel(const double *__restrict__ Y, i64 n, i64 row0,
                                                               i64 rows, const double *__restrict__ sorted,
                                                               i64 sstride, const u32 *__restrict__ nanrow,
-                                                              int nchunks, u64 *__restrict__ totals) {
+                                                              int nchunks, int qc0, int nqc,
+                                                              u64 *__restrict__ totals) {
     constexpr int E = BIG_E, LE = BigCfg::LE, WB = BigCfg::WB, N = BIG_C;
     extern __shared__ double Sm[];
     const int t = threadIdx.x;
-    const int qc = blockIdx.x % nchunks;
-    const int rgroups = gridDim.x / nchunks;
+    // only the curve chunks [qc0, qc0 + nqc) hold targets
+    const int qc = qc0 + (int)(blockIdx.x % nqc);
+    const int rgroups = gridDim.x / nqc;
     const i64 qbase = (i64)qc * BIG_C;
     const int nq = (int)((n - qbase) < BIG_C ? (n - qbase) : BIG_C);
     const double INF = __builtin_huge_val();
@@ -82,7 +84,7 @@ __global__ __launch_bounds__(BIG_NT) void chunk_search_kernel(const double *__re
 #pragma unroll
         for (int j = 0; j < J - 1; ++j) acc[e][j] = 0;
 
-    for (i64 rb = blockIdx.x / nchunks; rb < rows; rb += rgroups) {
+    for (i64 rb = blockIdx.x / nqc; rb < rows; rb += rgroups) {
         const double *xp = Y + (row0 + rb) * n + qbase + t;
         double x[E];
         u32 lo[E], hi[E];
@@ -137,11 +139,11 @@ __global__ __launch_bounds__(BIG_NT) void chunk_search_kernel(const double *__re
 
 // out[q*(J-1)+j] = totals[j][targets[q]]
 __global__ __launch_bounds__(256) void big_gather_kernel(const u64 *__restrict__ totals, i64 n, int jc,
-                                                         const i64 *__restrict__ targets, i64 m,
+                                                         const i64 *__restrict__ targets, i64 tbegin, i64 m,
                                                          u64 *__restrict__ out) {
     i64 q = (i64)blockIdx.x * 256 + threadIdx.x;
     if (q >= m) return;
-    i64 i = targets ? targets[q] : q;
+    i64 i = targets ? targets[q] : tbegin + q;
     for (int j = 0; j < jc; ++j) out[q * jc + j] = totals[(size_t)j * n + i];
 }
 
@@ -171,7 +173,7 @@ size_t mbd_rank_big_workspace_bytes(i64 T, i64 n, int J) {
     return b + 1024;
 }
 
-int launch_mbd_rank_big(const double *Y, i64 T, i64 n, const i64 *targets, i64 m, int J,
+int launch_mbd_rank_big(const double *Y, i64 T, i64 n, const i64 *targets, i64 tbegin, i64 m, int J,
                         u64 *out, void *ws, size_t ws_bytes, hipStream_t s) {
     if (!mbd_rank_big_supported(T, n, J)) return fail(SD_ERR_UNSUPPORTED, "chunked rank kernel covers n > 16384, J in {2,3}");
     const i64 nch = big_nchunks(n);
@@ -199,21 +201,26 @@ int launch_mbd_rank_big(const double *Y, i64 T, i64 n, const i64 *targets, i64 m
         SD_HIP(hipMemsetAsync(nanrow, 0, (size_t)rows * 4, s));
         hipLaunchKernelGGL(ksort, dim3((unsigned)nch, (unsigned)rows), dim3(BIG_NT), BigCfg::LDS_BYTES, s, Y, n, row0,
                            sorted, sstride, nanrow);
-        // persistent search grid: a multiple of nchunks, about one workgroup per CU
-        i64 rgroups = cus / nch;
+        // persistent search grid: a multiple of the number of target chunks, about one workgroup per CU.
+        // An explicit target list may point anywhere, so every chunk is searched; a contiguous block
+        // (targets == NULL) restricts the search to the chunks it overlaps.
+        i64 qc0 = targets ? 0 : tbegin / BIG_C;
+        i64 qc1 = targets ? nch : (tbegin + m + BIG_C - 1) / BIG_C;
+        i64 nqc = qc1 - qc0;
+        i64 rgroups = cus / nqc;
         if (rgroups < 1) rgroups = 1;
         if (rgroups > rows) rgroups = rows;
-        unsigned G = (unsigned)(rgroups * nch);
+        unsigned G = (unsigned)(rgroups * nqc);
         if (J == 2)
             hipLaunchKernelGGL(ks2, dim3(G), dim3(BIG_NT), BigCfg::LDS_BYTES, s, Y, n, row0, rows, sorted, sstride,
-                               nanrow, (int)nch, totals);
+                               nanrow, (int)nch, (int)qc0, (int)nqc, totals);
         else
             hipLaunchKernelGGL(ks3, dim3(G), dim3(BIG_NT), BigCfg::LDS_BYTES, s, Y, n, row0, rows, sorted, sstride,
-                               nanrow, (int)nch, totals);
+                               nanrow, (int)nch, (int)qc0, (int)nqc, totals);
         SD_HIP(hipGetLastError());
     }
     hipLaunchKernelGGL(big_gather_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s, totals, n, J - 1, targets,
-                       m, out);
+                       tbegin, m, out);
     SD_HIP(hipGetLastError());
     return SD_OK;
 }

@@ -59,7 +59,7 @@ static int check_matrix(const double *X, i64 T, i64 n, i64 st, i64 sn, const i64
     if (!((sn == 1 && st >= n) || (st == 1 && sn >= T)))
         return fail(SD_ERR_INVALID, "matrix must be time-major (sn=1, st>=n) or curve-major (st=1, sn>=T)");
     if (m < 0) return fail(SD_ERR_INVALID, "m < 0");
-    if (!targets && m != n) return fail(SD_ERR_INVALID, "targets=NULL requires m == n");
+    if (targets == nullptr && m != n) return fail(SD_ERR_INVALID, "targets=NULL requires m == n");
     return SD_OK;
 }
 
@@ -149,11 +149,14 @@ size_t sd_mbd_workspace_bytes(int64_t T, int64_t n, int64_t st, int64_t sn, int6
     return b + 1024;
 }
 
-int sd_mbd_counts(const double *X, int64_t T, int64_t n, int64_t st, int64_t sn,
-                  const int64_t *targets, int64_t m, int J, int algo,
-                  int64_t *out, void *ws, size_t ws_bytes, void *stream) {
-    int rc = check_matrix(X, T, n, st, sn, targets, m);
+static int mbd_counts_impl(const double *X, int64_t T, int64_t n, int64_t st, int64_t sn,
+                           const int64_t *targets, int64_t tbegin, int64_t m, int J, int algo,
+                           int64_t *out, void *ws, size_t ws_bytes, void *stream) {
+    int rc = check_matrix(X, T, n, st, sn, targets ? targets : (const i64 *)1, m);
     if (rc) return rc;
+    if (!targets && (tbegin < 0 || tbegin + m > n))
+        return fail(SD_ERR_INVALID, "target block [%lld, %lld) outside [0, %lld)", (long long)tbegin,
+                    (long long)(tbegin + m), (long long)n);
     if ((rc = check_count_range(T, n, J))) return rc;
     if (!out) return fail(SD_ERR_INVALID, "out is null");
     if (algo < SD_MBD_AUTO || algo > SD_MBD_RANK) return fail(SD_ERR_INVALID, "unknown algo %d", algo);
@@ -172,7 +175,7 @@ int sd_mbd_counts(const double *X, int64_t T, int64_t n, int64_t st, int64_t sn,
         size_t need = mbd_rank_big_workspace_bytes(T, n, J);
         void *rws = cv.take(need);
         if (!rws) return fail(SD_ERR_WORKSPACE, "workspace too small for the chunked rank kernel");
-        return launch_mbd_rank_big(Y, T, n, targets, m, J, (u64 *)out, rws, need, s);
+        return launch_mbd_rank_big(Y, T, n, targets, tbegin, m, J, (u64 *)out, rws, need, s);
     }
     if (a == SD_MBD_RANK) {
         if (!mbd_rank_supported(T, n, J))
@@ -180,12 +183,25 @@ int sd_mbd_counts(const double *X, int64_t T, int64_t n, int64_t st, int64_t sn,
         size_t need = mbd_rank_workspace_bytes(T, n, J);
         void *rws = cv.take(need);
         if (need && !rws) return fail(SD_ERR_WORKSPACE, "workspace too small for the rank kernel");
-        return launch_mbd_rank(Y, T, n, targets, m, J, (u64 *)out, rws, need, s);
+        return launch_mbd_rank(Y, T, n, targets, tbegin, m, J, (u64 *)out, rws, need, s);
     }
     u32 *nan_cnt = (u32 *)cv.take((size_t)T * 4);
     if (!nan_cnt) return fail(SD_ERR_WORKSPACE, "workspace too small (nan counts)");
     if ((rc = launch_nan_count_rows(Y, T, n, nan_cnt, s))) return rc;
-    return launch_mbd_pairwise(Y, T, n, targets, m, J, nan_cnt, (u64 *)out, s);
+    return launch_mbd_pairwise(Y, T, n, targets, tbegin, m, J, nan_cnt, (u64 *)out, s);
+}
+
+int sd_mbd_counts(const double *X, int64_t T, int64_t n, int64_t st, int64_t sn,
+                  const int64_t *targets, int64_t m, int J, int algo,
+                  int64_t *out, void *ws, size_t ws_bytes, void *stream) {
+    if (!targets && m != n) return fail(SD_ERR_INVALID, "targets=NULL requires m == n");
+    return mbd_counts_impl(X, T, n, st, sn, targets, 0, m, J, algo, out, ws, ws_bytes, stream);
+}
+
+int sd_mbd_counts_range(const double *X, int64_t T, int64_t n, int64_t st, int64_t sn,
+                        int64_t target_begin, int64_t m, int J, int algo,
+                        int64_t *out, void *ws, size_t ws_bytes, void *stream) {
+    return mbd_counts_impl(X, T, n, st, sn, nullptr, target_begin, m, J, algo, out, ws, ws_bytes, stream);
 }
 
 int sd_above_below(const double *X, int64_t T, int64_t n, int64_t st, int64_t sn,

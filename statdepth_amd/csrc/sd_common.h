@@ -47,18 +47,19 @@ int launch_to_time_major(const double *X, i64 T, i64 n, i64 st, i64 sn, double *
 // per-row NaN counts of a time-major matrix, plus a global any-NaN counter
 int launch_nan_count_rows(const double *Y, i64 T, i64 n, u32 *nan_cnt, hipStream_t s);
 // K1+K2 pairwise
-int launch_mbd_pairwise(const double *Y, i64 T, i64 n, const i64 *targets, i64 m, int J,
+// targets == nullptr means the contiguous block [tbegin, tbegin + m)
+int launch_mbd_pairwise(const double *Y, i64 T, i64 n, const i64 *targets, i64 tbegin, i64 m, int J,
                         const u32 *nan_cnt, u64 *out, hipStream_t s);
 int launch_above_below(const double *Y, i64 T, i64 n, const i64 *targets, i64 m, u32 *AB, hipStream_t s);
 // K1+K2 rank formulation
 size_t mbd_rank_workspace_bytes(i64 T, i64 n, int J);
 bool mbd_rank_supported(i64 T, i64 n, int J);
-int launch_mbd_rank(const double *Y, i64 T, i64 n, const i64 *targets, i64 m, int J,
+int launch_mbd_rank(const double *Y, i64 T, i64 n, const i64 *targets, i64 tbegin, i64 m, int J,
                     u64 *out, void *ws, size_t ws_bytes, hipStream_t s);
 // K1+K2 rank formulation for n > 16384 (chunked)
 bool mbd_rank_big_supported(i64 T, i64 n, int J);
 size_t mbd_rank_big_workspace_bytes(i64 T, i64 n, int J);
-int launch_mbd_rank_big(const double *Y, i64 T, i64 n, const i64 *targets, i64 m, int J,
+int launch_mbd_rank_big(const double *Y, i64 T, i64 n, const i64 *targets, i64 tbegin, i64 m, int J,
                         u64 *out, void *ws, size_t ws_bytes, hipStream_t s);
 // K3 strict
 size_t bd_strict_workspace_bytes(i64 T, i64 n, i64 m, int J);

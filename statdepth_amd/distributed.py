@@ -17,8 +17,8 @@ def _dist():
 
 
 def _default_compute(X_all, targets, J, algo):
-    """HIP path: counts of `targets` within the gathered matrix (device tensor in, device tensor out)."""
-    return engine.mbd_counts(X_all, targets, J=J, algo=algo, return_tensor=True)
+    """HIP path: totals of the contiguous target block within the gathered matrix (device tensors)."""
+    return engine.mbd_counts_range(X_all, int(targets[0]), len(targets), J=J, algo=algo, return_tensor=True)
 
 
 def gather_curve_blocks(X_loc, group=None, sizes=None):
@@ -39,6 +39,14 @@ def gather_curve_blocks(X_loc, group=None, sizes=None):
         sizes = szt.cpu().tolist()
     sizes = [int(v) for v in sizes]
     assert len(sizes) == world and sizes[dist.get_rank(group)] == n_loc
+    offsets = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    if min(sizes) == max(sizes):
+        # equal blocks: gather the time-major blocks as they lie, then one strided copy lays the rows out
+        recv = torch.empty((world * T, n_loc), dtype=X_loc.dtype, device=X_loc.device)
+        dist.all_gather_into_tensor(recv, X_loc.contiguous(), group=group)
+        X_all = torch.empty((T, world * n_loc), dtype=X_loc.dtype, device=X_loc.device)
+        X_all.view(T, world, n_loc).copy_(recv.view(world, T, n_loc).permute(1, 0, 2))
+        return X_all, offsets
     nmax = max(sizes)
     # blocks travel curve-major ([n_loc, T] rows are whole curves) so a ragged tail is plain padding
     send = torch.zeros((nmax, T), dtype=X_loc.dtype, device=X_loc.device)
@@ -46,15 +54,99 @@ def gather_curve_blocks(X_loc, group=None, sizes=None):
     recv = torch.empty((world * nmax, T), dtype=X_loc.dtype, device=X_loc.device)
     dist.all_gather_into_tensor(recv, send, group=group)
     recv = recv.view(world, nmax, T)
-    offsets = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
     X_all = torch.empty((T, int(offsets[-1])), dtype=X_loc.dtype, device=X_loc.device)
     for r in range(world):
         X_all[:, offsets[r]:offsets[r + 1]].copy_(recv[r, :sizes[r]].t())
     return X_all, offsets
 
 
-def sharded_mbd_counts(X_loc, J=2, algo="auto", group=None, gather_result=False, sizes=None, _compute=None):
+def _time_slices(T, world):
+    """Contiguous split of the T timepoints over the ranks (first T % world ranks get one more)."""
+    base, extra = divmod(T, world)
+    cnt = [base + (1 if r < extra else 0) for r in range(world)]
+    off = np.concatenate([[0], np.cumsum(cnt)]).astype(np.int64)
+    return cnt, off
+
+
+def exchange_to_time_slices(X_loc, sizes, group=None):
+    """All-to-all that turns curve blocks into time slices.
+
+    In: this rank's curves X_loc [T, n_loc] (time-major).  Out: X_rows [T_me, n] = ALL curves at this
+    rank's timepoints (rank blocks side by side), plus the column offsets.  Each rank sends only
+    (world-1)/world of its block and receives the same amount: 1/world of an all-gather's traffic.
+    """
+    import torch
+    dist = _dist()
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    T, n_loc = X_loc.shape
+    cnt, toff = _time_slices(T, world)
+    offsets = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    t_me = cnt[rank]
+    send = X_loc.contiguous().view(-1)                       # rows of destination s are contiguous
+    in_split = [cnt[s] * n_loc for s in range(world)]
+    out_split = [t_me * int(sizes[r]) for r in range(world)]
+    recv = torch.empty(int(sum(out_split)), dtype=X_loc.dtype, device=X_loc.device)
+    dist.all_to_all_single(recv, send, output_split_sizes=out_split, input_split_sizes=in_split, group=group)
+    n = int(offsets[-1])
+    X_rows = torch.empty((t_me, n), dtype=X_loc.dtype, device=X_loc.device)
+    if min(sizes) == max(sizes):
+        X_rows.view(t_me, world, n_loc).copy_(recv.view(world, t_me, n_loc).permute(1, 0, 2))
+    else:
+        pos = 0
+        for r in range(world):
+            blk = recv[pos:pos + out_split[r]].view(t_me, int(sizes[r]))
+            X_rows[:, offsets[r]:offsets[r + 1]].copy_(blk)
+            pos += out_split[r]
+    return X_rows, offsets
+
+
+def _default_compute_all(X_rows, J, algo):
+    """HIP path: totals of every curve over the given rows (device tensors)."""
+    return engine.mbd_counts(X_rows, None, J=J, algo=algo, return_tensor=True)
+
+
+def sharded_mbd_counts_time(X_loc, J=2, algo="auto", group=None, sizes=None, _compute_all=None):
+    """Time-sharded form of the same totals (the right decomposition for the rank kernels).
+
+    The rank formulation sorts whole rows, so splitting the TARGETS would make every GPU sort every
+    row.  Splitting the TIMEPOINTS divides the sort work: an all-to-all hands rank s all curves at its
+    timepoints, it computes per-curve partial totals over those rows, and a reduce-scatter (int64 sum)
+    returns to every rank the totals of its own curves.  Integer sums commute: results are identical
+    to the target-sharded and single-GPU paths.
+    """
+    import torch
+    dist = _dist()
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    T, n_loc = X_loc.shape
+    if sizes is None:
+        szt = torch.zeros(world, dtype=torch.int64, device=X_loc.device)
+        dist.all_gather_into_tensor(szt, torch.tensor([n_loc], dtype=torch.int64, device=X_loc.device), group=group)
+        sizes = szt.cpu().tolist()
+    sizes = [int(v) for v in sizes]
+    X_rows, offsets = exchange_to_time_slices(X_loc, sizes, group)
+    n = int(offsets[-1])
+    if X_rows.shape[0] > 0:
+        part = (_compute_all or _default_compute_all)(X_rows, J, algo)
+        if not isinstance(part, torch.Tensor):
+            part = torch.as_tensor(np.asarray(part), device=X_loc.device)
+    else:
+        part = torch.zeros((n, J - 1), dtype=torch.int64, device=X_loc.device)
+    part = part.contiguous()
+    if min(sizes) == max(sizes) and dist.get_backend(group) == "nccl":
+        out = torch.empty((n_loc, J - 1), dtype=torch.int64, device=X_loc.device)
+        dist.reduce_scatter_tensor(out, part, op=dist.ReduceOp.SUM, group=group)
+        return out
+    dist.all_reduce(part, op=dist.ReduceOp.SUM, group=group)     # ragged blocks / gloo: reduce, then slice
+    return part[offsets[rank]:offsets[rank + 1]].clone()
+
+
+def sharded_mbd_counts(X_loc, J=2, algo="auto", group=None, gather_result=False, sizes=None, mode="auto",
+                       _compute=None, _compute_all=None):
     """MBD containment totals of this rank's curves against the union of all ranks' curves.
+
+    mode: "targets" (all-gather of curve blocks, each rank computes its own targets: the pairwise
+    kernel's natural split), "time" (all-to-all + reduce-scatter: the rank kernels' natural split, see
+    sharded_mbd_counts_time) or "auto" (time when J <= 3 and there are at least as many timepoints as ranks).
 
     Returns int64 [n_loc, J-1] (device of X_loc), or with gather_result=True the full
     [n, J-1] array on every rank in global curve order.
@@ -63,15 +155,26 @@ def sharded_mbd_counts(X_loc, J=2, algo="auto", group=None, gather_result=False,
     import torch
     dist = _dist()
     rank = dist.get_rank(group)
-    X_all, offsets = gather_curve_blocks(X_loc, group, sizes)
-    targets = np.arange(offsets[rank], offsets[rank + 1], dtype=np.int64)
-    compute = _compute or _default_compute
-    local = compute(X_all, targets, J, algo)
-    if not isinstance(local, torch.Tensor):
-        local = torch.as_tensor(np.asarray(local), device=X_loc.device)
+    world = dist.get_world_size(group)
+    if mode == "auto":
+        mode = "time" if (J <= 3 and algo != "pairwise" and X_loc.shape[0] >= world) else "targets"
+    if mode == "time":
+        if sizes is None:
+            szt = torch.zeros(world, dtype=torch.int64, device=X_loc.device)
+            dist.all_gather_into_tensor(szt, torch.tensor([X_loc.shape[1]], dtype=torch.int64, device=X_loc.device),
+                                        group=group)
+            sizes = szt.cpu().tolist()
+        local = sharded_mbd_counts_time(X_loc, J=J, algo=algo, group=group, sizes=sizes, _compute_all=_compute_all)
+        offsets = np.concatenate([[0], np.cumsum([int(v) for v in sizes])]).astype(np.int64)
+    else:
+        X_all, offsets = gather_curve_blocks(X_loc, group, sizes)
+        targets = np.arange(offsets[rank], offsets[rank + 1], dtype=np.int64)
+        compute = _compute or _default_compute
+        local = compute(X_all, targets, J, algo)
+        if not isinstance(local, torch.Tensor):
+            local = torch.as_tensor(np.asarray(local), device=X_loc.device)
     if not gather_result:
         return local
-    world = dist.get_world_size(group)
     sizes = np.diff(offsets)
     nmax = int(sizes.max())
     send = torch.zeros((nmax, J - 1), dtype=torch.int64, device=X_loc.device)
@@ -82,7 +185,8 @@ def sharded_mbd_counts(X_loc, J=2, algo="auto", group=None, gather_result=False,
     return torch.cat([recv[r, :int(sizes[r])] for r in range(world)], dim=0)
 
 
-def sharded_functional_depth(df_local, J=2, relax=True, algo="auto", group=None, _compute=None):
+def sharded_functional_depth(df_local, J=2, relax=True, algo="auto", group=None, mode="auto", _compute=None,
+                             _compute_all=None):
     """FunctionalDepth over curves sharded by column blocks: returns this rank's depth Series.
 
     Normalisation as the reference (_functional.py:229,253): / T / C(n, j) with n the GLOBAL number of curves.
@@ -94,9 +198,10 @@ def sharded_functional_depth(df_local, J=2, relax=True, algo="auto", group=None,
         raise NotImplementedError("sharded path covers relax=True (modified band depth)")
     dist = _dist()
     X = np.ascontiguousarray(df_local.to_numpy(dtype=np.float64))
-    dev = engine._device() if _compute is None else torch.device("cpu")
+    dev = engine._device() if (_compute is None and _compute_all is None) else torch.device("cpu")
     X_loc = torch.from_numpy(X).to(dev)
-    counts = sharded_mbd_counts(X_loc, J=J, algo=algo, group=group, _compute=_compute).cpu().numpy()
+    counts = sharded_mbd_counts(X_loc, J=J, algo=algo, group=group, mode=mode, _compute=_compute,
+                                _compute_all=_compute_all).cpu().numpy()
     n_tot = torch.tensor([X.shape[1]], dtype=torch.int64, device=dev)
     dist.all_reduce(n_tot, group=group)
     n, T = int(n_tot.item()), X.shape[0]

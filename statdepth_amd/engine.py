@@ -110,6 +110,23 @@ def mbd_counts(X, targets=None, J=2, algo="auto", device=None, return_tensor=Fal
     return out.cpu().numpy()
 
 
+def mbd_counts_range(X, target_begin, m, J=2, algo="auto", device=None, return_tensor=False):
+    """Totals for the contiguous target block [target_begin, target_begin + m) (sd_mbd_counts_range)."""
+    t = torch()
+    lib = _native.require_device()
+    M = to_device_matrix(X, device)
+    dev = M.device
+    a = ALGOS[algo] if isinstance(algo, str) else int(algo)
+    out = t.empty((m, J - 1), dtype=t.int64, device=dev)
+    wsb = lib.sd_mbd_workspace_bytes(M.T, M.n, M.st, M.sn, m, J, a)
+    ws = t.empty(max(int(wsb), 8), dtype=t.uint8, device=dev)
+    check(lib.sd_mbd_counts_range(M.tensor.data_ptr(), M.T, M.n, M.st, M.sn, int(target_begin), int(m), J, a,
+                                  out.data_ptr(), ws.data_ptr(), wsb, _stream_ptr(dev)))
+    if return_tensor:
+        return out
+    return out.cpu().numpy()
+
+
 def above_below(X, targets=None, device=None):
     """uint32 -> int64 [m, T, 2] strictly-above / strictly-below counts (sd_above_below)."""
     t = torch()

@@ -29,6 +29,11 @@ def _oracle_compute(X_all, targets, J, algo):
     return oracle.mbd_counts(X_all.cpu().numpy(), targets, J)
 
 
+def _oracle_compute_all(X_rows, J, algo):
+    import oracle
+    return oracle.mbd_counts(X_rows.cpu().numpy(), None, J)
+
+
 def _worker(rank, world, port, splits, J, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -40,10 +45,15 @@ def _worker(rank, world, port, splits, J, q):
         X = np.round(rng.normal(size=(T, n)).cumsum(axis=0), 1)
         lo, hi = splits[rank], splits[rank + 1]
         X_loc = torch.from_numpy(np.ascontiguousarray(X[:, lo:hi]))
-        loc = sharded_mbd_counts(X_loc, J=J, _compute=_oracle_compute)
-        full = sharded_mbd_counts(X_loc, J=J, gather_result=True, _compute=_oracle_compute)
+        hooks = dict(_compute=_oracle_compute, _compute_all=_oracle_compute_all)
+        loc = sharded_mbd_counts(X_loc, J=J, mode="targets", **hooks)
+        full = sharded_mbd_counts(X_loc, J=J, mode="targets", gather_result=True, **hooks)
+        # time-sharded exchange (all-to-all + reduction): same integers
+        loc_t = sharded_mbd_counts(X_loc, J=J, mode="time", **hooks)
+        full_t = sharded_mbd_counts(X_loc, J=J, mode="auto", gather_result=True, **hooks)
+        assert (loc_t == loc).all() and (full_t == full).all()
         df = pd.DataFrame(X[:, lo:hi], columns=[f"c{i}" for i in range(lo, hi)])
-        ser = sharded_functional_depth(df, J=J, relax=True, _compute=_oracle_compute)
+        ser = sharded_functional_depth(df, J=J, relax=True, **hooks)
         q.put((rank, loc.numpy(), full.numpy(), ser))
     except Exception as e:   # surface the failure instead of letting the parent time out
         q.put((rank, repr(e), None, None))

@@ -140,6 +140,18 @@ def test_mbd_nan_inf_ties(eng, oracle, algo):
         assert (eng.mbd_counts(X, None, J, algo=algo) == oracle.mbd_counts(X, None, J)).all()
 
 
+def test_mbd_counts_range_vs_oracle(eng, oracle):
+    """Contiguous target block (the sharded path's form), all three kernels."""
+    rng = np.random.default_rng(31)
+    for (T, n, lo, m) in [(7, 500, 100, 250), (3, 20000, 9000, 10000), (2, 40000, 16000, 20000), (2, 40000, 0, 5)]:
+        X = np.round(rng.normal(size=(T, n)).cumsum(axis=0), 1)
+        want = oracle.mbd_counts(X, np.arange(lo, lo + m), 2)
+        for algo in ("pairwise", "rank", "auto"):
+            if algo == "pairwise" and n * m > 3e8:
+                continue
+            assert (eng.mbd_counts_range(X, lo, m, 2, algo=algo) == want).all()
+
+
 def test_mbd_high_J_pairwise(eng, oracle):
     rng = np.random.default_rng(5)
     X = rng.integers(0, 9, size=(12, 40)).astype(float)
