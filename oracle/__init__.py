@@ -52,6 +52,7 @@ def lib():
                                                   ctypes.c_long, ctypes.c_int, ctypes.c_double, c_ip]
         L.oracle_l1_depth.argtypes = [c_dp, ctypes.c_long, ctypes.c_int, c_lp, ctypes.c_long, c_dp]
         L.oracle_num_threads.restype = ctypes.c_int
+        L.oracle_set_num_threads.argtypes = [ctypes.c_int]
         _LIB = L
     return _LIB
 
@@ -91,6 +92,12 @@ def _targets(targets, n):
 
 def num_threads():
     return int(lib().oracle_num_threads())
+
+
+def set_num_threads(k):
+    """Threads used by the OpenMP loops (bench.py pins this to the box's CPU share)."""
+    lib().oracle_set_num_threads(int(k))
+    return num_threads()
 
 
 def band_enum(X, targets=None, J=2, relax=True):

@@ -41,6 +41,14 @@ static u64 binom_u64(u64 a, int k) {
     return c;
 }
 
+void oracle_set_num_threads(int k) {
+#ifdef _OPENMP
+    if (k > 0) omp_set_num_threads(k);
+#else
+    (void)k;
+#endif
+}
+
 int oracle_num_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();
