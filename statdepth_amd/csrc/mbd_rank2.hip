@@ -92,11 +92,11 @@ __global__ __launch_bounds__(NT) void mbd_rank2_kernel(const double *__restrict_
                 if (t + e * NT < n) {
                     double x = xp[e * NT];
                     if (x == x) {
-                        int lo = r2_bound<N, LE, false, false>(Sm, n_act, x, INF);   // x is in the row
+                        int lo = r2_bound<N, SlotPad<LE>, false, false>(Sm, n_act, x, INF);   // x is in the row
                         // upper bound: one probe settles it unless x is tied with its successor
                         int hi = lo + 1;
                         double nx = (hi < n_act) ? Sm[r2_phys<LE>(hi)] : INF;
-                        if (hi < n_act && nx <= x) hi = r2_bound<N, LE, true>(Sm, n_act, x, INF);
+                        if (hi < n_act && nx <= x) hi = r2_bound<N, SlotPad<LE>, true>(Sm, n_act, x, INF);
                         u32 B = (u32)lo;
                         // keys <= x within [0, n_act) are real non-NaN values unless x = +inf
                         u32 A = (x == INF) ? 0u : (u32)(n - hi) - nnan;

@@ -69,7 +69,7 @@ __global__ __launch_bounds__(BIG_NT) void chunk_search_kernel(const double *__re
                                                               i64 sstride, const u32 *__restrict__ nanrow,
                                                               int nchunks, int qc0, int nqc,
                                                               u64 *__restrict__ totals) {
-    constexpr int E = BIG_E, LE = BigCfg::LE, WB = BigCfg::WB, N = BIG_C;
+    constexpr int E = BIG_E, WB = BigCfg::WB, N = BIG_C;
     extern __shared__ double Sm[];
     const int t = threadIdx.x;
     // only the curve chunks [qc0, qc0 + nqc) hold targets
@@ -100,17 +100,17 @@ __global__ __launch_bounds__(BIG_NT) void chunk_search_kernel(const double *__re
             const int n_act = ((nc + WB - 1) / WB) * WB;
             const double *src = sorted + rb * sstride + base;
             __syncthreads();                          // previous chunk's searches are done
-            for (int p = t; p < n_act; p += BIG_NT) Sm[r2_phys<LE>(p)] = src[p];
+            for (int p = t; p < n_act; p += BIG_NT) Sm[r2_swz(p)] = src[p];
             __syncthreads();
 #pragma unroll
             for (int e = 0; e < E; ++e) {
                 if ((e & 3) == 0) __builtin_amdgcn_sched_barrier(0);
                 if (t + e * BIG_NT < nq && x[e] == x[e]) {
-                    int l = r2_bound<N, LE, false>(Sm, n_act, x[e], INF);
+                    int l = r2_bound<N, SlotSwz, false>(Sm, n_act, x[e], INF);
                     int h = l;
                     // keys equal to x in this chunk?  (always true once: in x's own chunk)
-                    double nx = (l < n_act) ? Sm[r2_phys<LE>(l)] : INF;
-                    if (l < n_act && nx <= x[e]) h = r2_bound<N, LE, true>(Sm, n_act, x[e], INF);
+                    double nx = (l < n_act) ? Sm[r2_swz(l)] : INF;
+                    if (l < n_act && nx <= x[e]) h = r2_bound<N, SlotSwz, true>(Sm, n_act, x[e], INF);
                     lo[e] += (u32)l;
                     hi[e] += (u32)h;
                 }

@@ -181,22 +181,38 @@ struct R2Sorter {
     }
 };
 
-// Fixed-depth descent over the sorted LDS image restricted to [0, n_act): number of keys < x
+// Alternative slot map for a search image that is filled by a plain coalesced copy (mbd_rank_big): the
+// probes of a descent are p = m * 2^j - 1, which a linear or padded image puts on one or two banks for
+// the upper levels; XOR-ing bits 5..9 and 10..14 of p into the low five bits spreads them.  Measured:
+// -13 % on the chunked kernel; on mbd_rank2 (image written from the sort's registers, one extra
+// barrier, more address arithmetic per probe) the padded image is faster, so that kernel keeps it.
+__device__ __forceinline__ int r2_swz(int p) { return p ^ (((p >> 5) ^ (p >> 10)) & 31); }
+
+// Fixed-depth descent over the sorted search image restricted to [0, n_act): number of keys < x
 // (INCL = false) or <= x (INCL = true).  The descent alone tops out at N - 1; FINAL adds the
 // closing probe that makes N reachable.  It can be omitted for the strict count when x itself
 // is one of the keys (then at most N - 1 keys are below it).
-template <int N, int LE, bool INCL, bool FINAL = true>
+// SLOT: slot map of the image: SlotPad<LE> (the transpose image, mbd_rank2) or SlotSwz (mbd_rank_big).
+template <int LE>
+struct SlotPad {
+    static __device__ __forceinline__ int at(int p) { return r2_phys<LE>(p); }
+};
+struct SlotSwz {
+    static __device__ __forceinline__ int at(int p) { return r2_swz(p); }
+};
+
+template <int N, class SLOT, bool INCL, bool FINAL = true>
 __device__ __forceinline__ int r2_bound(const double *Sm, int n_act, double x, double big) {
     int c = 0;
 #pragma unroll
     for (int s = N >> 1; s >= 1; s >>= 1) {
         int pos = c + s - 1;
-        double a = (pos < n_act) ? Sm[r2_phys<LE>(pos)] : big;
+        double a = (pos < n_act) ? Sm[SLOT::at(pos)] : big;
         bool go = INCL ? (a <= x) : (a < x);
         c += go ? s : 0;
     }
     if (FINAL) {
-        double a = (c < n_act) ? Sm[r2_phys<LE>(c)] : big;
+        double a = (c < n_act) ? Sm[SLOT::at(c)] : big;
         bool go = INCL ? (a <= x) : (a < x);
         c += go ? 1 : 0;
     }
