@@ -89,8 +89,8 @@ def main():
     targets = torch.arange(rank * n_loc, (rank + 1) * n_loc, dtype=torch.int64, device=dev)
     out = torch.empty((n_loc, J - 1), dtype=torch.int64, device=dev)
     algo = ALGOS[args.algo]
-    wsb = lib.sd_mbd_workspace_bytes(T, n, n, 1, n_loc, J, algo)
-    ws = torch.empty(int(wsb), dtype=torch.uint8, device=dev)
+    wsb = 0 if use_dist else lib.sd_mbd_workspace_bytes(T, n, n, 1, n_loc, J, algo)
+    ws = torch.empty(max(int(wsb), 8), dtype=torch.uint8, device=dev)
     stream = torch.cuda.current_stream(dev)
 
     from statdepth_amd.distributed import sharded_mbd_counts
@@ -98,7 +98,9 @@ def main():
 
     def step():
         if use_dist:
-            # product multi-GPU path: RCCL all-gather of the curve blocks, then the local targets' totals
+            # product multi-GPU path (statdepth_amd/distributed.py): time-sharded for the rank kernels
+            # (RCCL all-to-all of curve blocks -> per-curve partial totals -> reduce-scatter), target-sharded
+            # (all-gather) for --algo pairwise
             out.copy_(sharded_mbd_counts(X_loc, J=J, algo=args.algo, sizes=sizes))
         else:
             check(lib.sd_mbd_counts(X_all.data_ptr(), T, n, n, 1, targets.data_ptr(), n_loc, J, algo,
@@ -142,7 +144,9 @@ def main():
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"MBD J={J}: {n} curves x {T} timepoints (n_loc={n_loc} targets per GPU), fp64 "
                                    f"random walks, time-major", "algorithm": used,
-                       "parallelism": f"targets sharded x{N}" + (", RCCL all-gather of curve blocks" if N > 1 else "")},
+                       "parallelism": (f"single GPU" if N == 1 else
+                                       (f"targets sharded x{N}, RCCL all-gather of curve blocks" if used == "pairwise" else
+                                        f"curves owned x{N}, timepoints sharded for the sort: RCCL all-to-all + reduce-scatter"))},
             "pair_timepoints_per_s": value * T,
             "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK, "traffic": pmc_traffic(kern, n, T, J) if N == 1 else None,

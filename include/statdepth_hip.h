@@ -97,6 +97,15 @@ int sd_mbd_counts_range(const double *X, int64_t T, int64_t n, int64_t st, int64
                         int64_t target_begin, int64_t m, int J, int algo,
                         int64_t *out, void *ws, size_t ws_bytes, void *stream);
 
+/* Band totals of m EXTERNAL curves Q (T x m, time-major dense) with respect to the n curves of X (time-major
+ * dense, st = n, sn = 1): every curve of X is an "other".  This is what the reference's homogeneity
+ * coefficients do |G| times with a temporary column (homogeneity.py:101-112,125-128: append g to F, call
+ * FunctionalDepth(to_compute=[g]), drop g) -- here one launch for all of G.
+ * out[q*(J-1)+(j-2)] = sum_t #{j-subsets of X's curves whose band contains Q[:,q] at t};
+ * depth of g within F u {g} = sum_j out/T / C(n+1, j) on the host (_functional.py:229,253). */
+int sd_mbd_external_counts(const double *X, int64_t T, int64_t n, const double *Q, int64_t m, int J,
+                           int64_t *out, void *ws, size_t ws_bytes, void *stream);
+
 /* Finest-granularity form of K1 (tests, diagnostics): AB[(q*T + t)*2 + {0,1}] =
  * (#curves strictly above, #strictly below) target q at t, as uint32. */
 int sd_above_below(const double *X, int64_t T, int64_t n, int64_t st, int64_t sn,

@@ -80,13 +80,15 @@ int launch_nan_count_rows(const double *Y, i64 T, i64 n, u32 *nan_cnt, hipStream
 constexpr int PW_THREADS = 256;
 constexpr int PW_TB = 4;   // timepoints per workgroup
 
+// Q != nullptr: the targets are EXTERNAL curves Q[t*m + q] (not members of Y); all n curves of Y are "others".
 template <int J, bool WRITE_AB>
 __global__ __launch_bounds__(PW_THREADS) void mbd_pairwise_kernel(
     const double *__restrict__ Y, i64 T, i64 n, const i64 *__restrict__ targets, i64 tbegin, i64 m,
-    const u32 *__restrict__ nan_cnt, u64 *__restrict__ out, u32 *__restrict__ AB) {
+    const u32 *__restrict__ nan_cnt, u64 *__restrict__ out, u32 *__restrict__ AB,
+    const double *__restrict__ Q) {
     i64 q = (i64)blockIdx.x * PW_THREADS + threadIdx.x;
     bool valid = q < m;
-    i64 tg = valid ? (targets ? targets[q] : tbegin + q) : 0;
+    i64 tg = (valid && !Q) ? (targets ? targets[q] : tbegin + q) : 0;
     i64 t0 = (i64)blockIdx.y * PW_TB;
     u64 acc[JMAX - 1];
 #pragma unroll
@@ -96,7 +98,7 @@ __global__ __launch_bounds__(PW_THREADS) void mbd_pairwise_kernel(
         i64 t = t0 + tt;
         if (t >= T) break;
         const double *__restrict__ row = Y + t * n;
-        double xq = row[tg];
+        double xq = Q ? Q[t * m + (valid ? q : 0)] : row[tg];
         u32 A = 0, B = 0;
         i64 i = 0;
         // wave-uniform addresses: the compiler issues scalar loads for row[i]
@@ -119,7 +121,7 @@ __global__ __launch_bounds__(PW_THREADS) void mbd_pairwise_kernel(
                 AB[(q * T + t) * 2 + 1] = B;
             }
         } else {
-            if (valid && xq == xq) band_counts_add<J>(A, B, nan_cnt[t], (u64)(n - 1), acc);
+            if (valid && xq == xq) band_counts_add<J>(A, B, nan_cnt[t], (u64)(Q ? n : n - 1), acc);
         }
     }
     if constexpr (!WRITE_AB) {
@@ -135,7 +137,18 @@ int launch_mbd_pairwise(const double *Y, i64 T, i64 n, const i64 *targets, i64 t
     SD_HIP(hipMemsetAsync(out, 0, sizeof(u64) * m * (J - 1), s));
     dim3 grid((unsigned)((m + PW_THREADS - 1) / PW_THREADS), (unsigned)((T + PW_TB - 1) / PW_TB));
     SD_DISPATCH_J(J, hipLaunchKernelGGL((mbd_pairwise_kernel<J_, false>), grid, dim3(PW_THREADS), 0, s,
-                                        Y, T, n, targets, tbegin, m, nan_cnt, out, (u32 *)nullptr));
+                                        Y, T, n, targets, tbegin, m, nan_cnt, out, (u32 *)nullptr,
+                                        (const double *)nullptr));
+    SD_HIP(hipGetLastError());
+    return SD_OK;
+}
+
+int launch_mbd_external(const double *Y, i64 T, i64 n, const double *Q, i64 m, int J, const u32 *nan_cnt, u64 *out,
+                        hipStream_t s) {
+    SD_HIP(hipMemsetAsync(out, 0, sizeof(u64) * m * (J - 1), s));
+    dim3 grid((unsigned)((m + PW_THREADS - 1) / PW_THREADS), (unsigned)((T + PW_TB - 1) / PW_TB));
+    SD_DISPATCH_J(J, hipLaunchKernelGGL((mbd_pairwise_kernel<J_, false>), grid, dim3(PW_THREADS), 0, s,
+                                        Y, T, n, (const i64 *)nullptr, (i64)0, m, nan_cnt, out, (u32 *)nullptr, Q));
     SD_HIP(hipGetLastError());
     return SD_OK;
 }
@@ -143,7 +156,7 @@ int launch_mbd_pairwise(const double *Y, i64 T, i64 n, const i64 *targets, i64 t
 int launch_above_below(const double *Y, i64 T, i64 n, const i64 *targets, i64 m, u32 *AB, hipStream_t s) {
     dim3 grid((unsigned)((m + PW_THREADS - 1) / PW_THREADS), (unsigned)((T + PW_TB - 1) / PW_TB));
     hipLaunchKernelGGL((mbd_pairwise_kernel<2, true>), grid, dim3(PW_THREADS), 0, s, Y, T, n, targets, (i64)0, m,
-                       (const u32 *)nullptr, (u64 *)nullptr, AB);
+                       (const u32 *)nullptr, (u64 *)nullptr, AB, (const double *)nullptr);
     SD_HIP(hipGetLastError());
     return SD_OK;
 }

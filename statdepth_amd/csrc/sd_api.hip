@@ -204,6 +204,22 @@ int sd_mbd_counts_range(const double *X, int64_t T, int64_t n, int64_t st, int64
     return mbd_counts_impl(X, T, n, st, sn, nullptr, target_begin, m, J, algo, out, ws, ws_bytes, stream);
 }
 
+int sd_mbd_external_counts(const double *X, int64_t T, int64_t n, const double *Q, int64_t m, int J,
+                           int64_t *out, void *ws, size_t ws_bytes, void *stream) {
+    if (!X || !Q || !out) return fail(SD_ERR_INVALID, "null pointer");
+    if (T <= 0 || n <= 0 || m < 0) return fail(SD_ERR_INVALID, "bad shape (T=%lld, n=%lld, m=%lld)", (long long)T,
+                                                (long long)n, (long long)m);
+    int rc = check_count_range(T, n + 1, J);
+    if (rc) return rc;
+    if (m == 0) return SD_OK;
+    Carver cv(ws, ws_bytes);
+    u32 *nan_cnt = (u32 *)cv.take((size_t)T * 4);
+    if (!nan_cnt) return fail(SD_ERR_WORKSPACE, "workspace too small (need T*4 + 256 bytes)");
+    hipStream_t s = (hipStream_t)stream;
+    if ((rc = launch_nan_count_rows(X, T, n, nan_cnt, s))) return rc;
+    return launch_mbd_external(X, T, n, Q, m, J, nan_cnt, (u64 *)out, s);
+}
+
 int sd_above_below(const double *X, int64_t T, int64_t n, int64_t st, int64_t sn,
                    const int64_t *targets, int64_t m, uint32_t *AB,
                    void *ws, size_t ws_bytes, void *stream) {

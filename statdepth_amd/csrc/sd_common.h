@@ -50,6 +50,9 @@ int launch_nan_count_rows(const double *Y, i64 T, i64 n, u32 *nan_cnt, hipStream
 // targets == nullptr means the contiguous block [tbegin, tbegin + m)
 int launch_mbd_pairwise(const double *Y, i64 T, i64 n, const i64 *targets, i64 tbegin, i64 m, int J,
                         const u32 *nan_cnt, u64 *out, hipStream_t s);
+// external targets Q (T x m, time-major) against the n curves of Y
+int launch_mbd_external(const double *Y, i64 T, i64 n, const double *Q, i64 m, int J, const u32 *nan_cnt, u64 *out,
+                        hipStream_t s);
 int launch_above_below(const double *Y, i64 T, i64 n, const i64 *targets, i64 m, u32 *AB, hipStream_t s);
 // K1+K2 rank formulation
 size_t mbd_rank_workspace_bytes(i64 T, i64 n, int J);

@@ -127,6 +127,25 @@ def mbd_counts_range(X, target_begin, m, J=2, algo="auto", device=None, return_t
     return out.cpu().numpy()
 
 
+def mbd_external_counts(X, Q, J=2, device=None):
+    """int64[m, J-1]: band totals of the m columns of Q (T x m) w.r.t. the n columns of X (sd_mbd_external_counts)."""
+    t = torch()
+    lib = _native.require_device()
+    dev = _device(device)
+    Xd = t.from_numpy(np.ascontiguousarray(np.asarray(X, dtype=np.float64))).to(dev)
+    Qd = t.from_numpy(np.ascontiguousarray(np.asarray(Q, dtype=np.float64))).to(dev)
+    T, n = Xd.shape
+    if Qd.dim() != 2 or Qd.shape[0] != T:
+        raise ValueError("Q must have the same number of timepoints as X")
+    m = Qd.shape[1]
+    out = t.empty((m, J - 1), dtype=t.int64, device=dev)
+    wsb = T * 4 + 1024
+    ws = t.empty(wsb, dtype=t.uint8, device=dev)
+    check(lib.sd_mbd_external_counts(Xd.data_ptr(), T, n, Qd.data_ptr(), m, J, out.data_ptr(), ws.data_ptr(), wsb,
+                                     _stream_ptr(dev)))
+    return out.cpu().numpy()
+
+
 def above_below(X, targets=None, device=None):
     """uint32 -> int64 [m, T, 2] strictly-above / strictly-below counts (sd_above_below)."""
     t = torch()

@@ -92,6 +92,34 @@ def test_golden_ksampled_reproduces_reference_blocks():
     assert_depths_close(got.to_numpy(), depths_of(fx), TOL)
 
 
+@pytest.mark.parametrize("name", golden_names(kind="homogeneity"))
+def test_golden_homogeneity(name):
+    """Caller of the hot path: P1/P2/P3 equal the reference's values; P3 is one batched launch."""
+    from statdepth_amd.homogeneity import FunctionalHomogeneity
+    fx = load_golden(name)
+    F, G = frame_df(fx["input"]["F"]), frame_df(fx["input"]["G"])
+    Fc, Gc = F.copy(), G.copy()
+    h = FunctionalHomogeneity([F], [G], method=fx["call"]["method"], relax=True, quiet=True).homogeneity()
+    got = np.asarray(h, dtype=float).ravel()
+    assert_depths_close(got, np.array(fx["value"], dtype=float), TOL)
+    assert F.equals(Fc) and G.equals(Gc)           # inputs are not mutated (the reference does mutate F)
+
+
+def test_external_counts_vs_oracle(eng, oracle):
+    """sd_mbd_external_counts == oracle depth counts of g inside F u {g}, for every g at once."""
+    rng = np.random.default_rng(12)
+    F = np.round(rng.normal(size=(19, 300)).cumsum(axis=0), 1)
+    G = np.round(rng.normal(size=(19, 70)).cumsum(axis=0) + 0.3, 1)
+    G[3, 5] = np.nan
+    F[7, 11] = np.nan
+    for J in (2, 3):
+        got = eng.mbd_external_counts(F, G, J=J)
+        for q in (0, 5, 33, 69):
+            Fg = np.concatenate([F, G[:, q:q + 1]], axis=1)
+            want = oracle.mbd_counts(Fg, [F.shape[1]], J)[0]
+            assert (got[q] == want).all()
+
+
 # ---------------------------------------------------------------- randomised, against the oracle
 def _cases():
     rng = np.random.default_rng(123)
