@@ -101,6 +101,8 @@ def mbd_counts(X, targets=None, J=2, algo="auto", device=None, return_tensor=Fal
     td, m, tp = _targets_dev(targets, M.n, dev)
     a = ALGOS[algo] if isinstance(algo, str) else int(algo)
     out = t.empty((m, J - 1), dtype=t.int64, device=dev)
+    if m == 0:
+        return out if return_tensor else out.cpu().numpy()
     wsb = lib.sd_mbd_workspace_bytes(M.T, M.n, M.st, M.sn, m, J, a)
     ws = t.empty(max(int(wsb), 8), dtype=t.uint8, device=dev)
     check(lib.sd_mbd_counts(M.tensor.data_ptr(), M.T, M.n, M.st, M.sn, tp, m, J, a,
@@ -169,6 +171,8 @@ def bd_strict_counts(X, targets=None, J=2, device=None):
     dev = M.device
     td, m, tp = _targets_dev(targets, M.n, dev)
     out = t.empty((m, J - 1), dtype=t.int64, device=dev)
+    if m == 0:
+        return out.cpu().numpy()
     wsb = lib.sd_bd_strict_j_workspace_bytes(M.T, M.n, M.st, M.sn, m, J)
     ws = t.empty(max(int(wsb), 8), dtype=t.uint8, device=dev)
     check(lib.sd_bd_strict_j_counts(M.tensor.data_ptr(), M.T, M.n, M.st, M.sn, tp, m, J,
@@ -196,6 +200,8 @@ def l1_depth(P, targets=None, device=None):
     n, d = Pd.shape
     td, m, tp = _targets_dev(targets, n, dev)
     out = t.empty(m, dtype=t.float64, device=dev)
+    if m == 0:
+        return out.cpu().numpy()
     check(lib.sd_l1_depth(Pd.data_ptr(), n, d, tp, m, out.data_ptr(), _stream_ptr(dev)))
     return out.cpu().numpy()
 
@@ -207,6 +213,8 @@ def pointcloud_simplex_counts(P, targets=None, tol=1e-7, samples=None, seed=0, d
     n, d = Pd.shape
     td, m, tp = _targets_dev(targets, n, dev)
     out = t.empty(m, dtype=t.int64, device=dev)
+    if m == 0:
+        return out.cpu().numpy()
     if samples is None:
         check(lib.sd_pointcloud_simplex_counts(Pd.data_ptr(), n, d, tp, m, tol, out.data_ptr(), _stream_ptr(dev)))
     else:
@@ -223,6 +231,8 @@ def multi_simplex_counts(P, targets=None, relax=True, tol=1e-7, samples=None, se
     n, T, d = Pd.shape
     td, m, tp = _targets_dev(targets, n, dev)
     out = t.empty(m, dtype=t.int64, device=dev)
+    if m == 0:
+        return out.cpu().numpy()
     if samples is None:
         check(lib.sd_multi_simplex_counts(Pd.data_ptr(), n, T, d, tp, m, int(bool(relax)), tol,
                                           out.data_ptr(), _stream_ptr(dev)))

@@ -265,3 +265,53 @@ def test_config2_scale_properties(eng, oracle):
     # without ties, ranks at each t are a permutation: sum_i [C(A,2)+C(B,2)] is the same at every t
     expect = T * (n * cmax // T - 2 * sum(k * (k - 1) // 2 for k in range(n)))
     assert int(full.sum()) == expect
+
+
+# ---------------------------------------------------------------- edge cases of the boundary
+def test_edge_cases_api(oracle):
+    from statdepth_amd import FunctionalDepth, PointcloudDepth
+    rng = np.random.default_rng(3)
+    # smallest legal problem: 2 timepoints... J must be < number of rows, so T >= 3 for J = 2
+    df = pd.DataFrame(rng.normal(size=(3, 3)), columns=["a", "b", "c"], index=[10, 20, 30])
+    for relax in (True, False):
+        got = FunctionalDepth([df], relax=relax)
+        assert_depths_close(got.to_numpy(), oracle.univariate_depths(df.to_numpy(), None, 2, relax), TOL)
+    # empty to_compute -> empty Series
+    e = FunctionalDepth([df], to_compute=[], relax=True)
+    assert len(e) == 0
+    # duplicated / reordered targets keep the caller's order
+    d = FunctionalDepth([df], to_compute=["c", "a", "c"], relax=True)
+    assert list(d.index) == ["c", "a", "c"] and d.iloc[0] == d.iloc[2]
+    # integer dtype frames and constant data (everything tied): every band contains everything
+    di = pd.DataFrame(np.ones((4, 6), dtype=np.int64))
+    assert_depths_close(FunctionalDepth([di], relax=True).to_numpy(), oracle.univariate_depths(np.ones((4, 6)), None, 2, True), TOL)
+    assert_depths_close(FunctionalDepth([di], relax=False).to_numpy(), oracle.univariate_depths(np.ones((4, 6)), None, 2, False), TOL)
+    # J larger than the number of other curves: those terms vanish (C(n-1, J) = 0 subsets)
+    dj = pd.DataFrame(rng.normal(size=(6, 3)))
+    assert_depths_close(FunctionalDepth([dj], J=3, relax=True).to_numpy(),
+                        oracle.univariate_depths(dj.to_numpy(), None, 3, True), TOL)
+    # all-NaN curve, and huge / tiny magnitudes
+    dn = pd.DataFrame(rng.normal(size=(5, 7)))
+    dn.iloc[:, 2] = np.nan
+    dn.iloc[1, 4] = 1e308
+    dn.iloc[2, 5] = -1e-320
+    for relax in (True, False):
+        assert_depths_close(FunctionalDepth([dn], relax=relax).to_numpy(),
+                            oracle.univariate_depths(dn.to_numpy(), None, 2, relax), TOL)
+    # point cloud with exactly d + 2 points and labelled index
+    pc = pd.DataFrame(rng.normal(size=(4, 2)), index=list("wxyz"))
+    got = PointcloudDepth(pc)
+    assert list(got.index) == list("wxyz")
+    assert_depths_close(got.to_numpy(), oracle.pointcloud_depths(pc.to_numpy()), TOL)
+    assert len(PointcloudDepth(pc, to_compute=[], containment="l1")) == 0
+
+
+def test_overflow_is_reported_not_wrapped():
+    """T*C(n-1,J) >= 2^63 must raise instead of returning wrapped integers."""
+    from statdepth_amd import engine
+    from statdepth_amd._native import StatdepthHipError, SD_ERR_OVERFLOW
+    import torch
+    X = torch.zeros((5, 200000), dtype=torch.float64, device="cuda")
+    with pytest.raises(StatdepthHipError) as ei:
+        engine.mbd_counts(X, [0, 1], J=4, algo="pairwise")
+    assert ei.value.code == SD_ERR_OVERFLOW
