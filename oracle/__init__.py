@@ -50,6 +50,8 @@ def lib():
                                                        ctypes.c_double, c_ip]
         L.oracle_multi_simplex_counts.argtypes = [c_dp, ctypes.c_long, ctypes.c_long, ctypes.c_int, c_lp,
                                                   ctypes.c_long, ctypes.c_int, ctypes.c_double, c_ip]
+        L.oracle_simplex_sampled.argtypes = [c_dp, ctypes.c_long, ctypes.c_long, ctypes.c_int, c_lp, ctypes.c_long,
+                                             ctypes.c_int, ctypes.c_double, ctypes.c_long, ctypes.c_uint64, c_ip]
         L.oracle_l1_depth.argtypes = [c_dp, ctypes.c_long, ctypes.c_int, c_lp, ctypes.c_long, c_dp]
         L.oracle_num_threads.restype = ctypes.c_int
         L.oracle_set_num_threads.argtypes = [ctypes.c_int]
@@ -170,6 +172,20 @@ def multi_simplex_counts(P, targets=None, relax=True, tol=DEFAULT_TOL):
     tg = _targets(targets, n)
     out = np.zeros(len(tg), dtype=np.int64)
     rc = lib().oracle_multi_simplex_counts(_dp(P), n, T, d, _lp(tg), len(tg), int(bool(relax)), tol, _ip(out))
+    assert rc == 0
+    return out
+
+
+def simplex_sampled(P, targets=None, relax=True, tol=DEFAULT_TOL, samples=64, seed=0):
+    """Seeded subset-sampling estimator (build's own definition; see oracle.c).  P: (n, d) or (n, T, d)."""
+    P = np.ascontiguousarray(P, dtype=np.float64)
+    if P.ndim == 2:
+        P = P[:, None, :]
+    n, T, d = P.shape
+    tg = _targets(targets, n)
+    out = np.zeros(len(tg), dtype=np.int64)
+    rc = lib().oracle_simplex_sampled(_dp(P), n, T, d, _lp(tg), len(tg), int(bool(relax)), tol, int(samples),
+                                      int(seed), _ip(out))
     assert rc == 0
     return out
 

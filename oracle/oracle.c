@@ -460,6 +460,66 @@ int oracle_multi_simplex_counts(const double *P, long n, long T, int d, const lo
 }
 
 /* --------------------------------------------------------------------------
+ * Seeded subset-sampling estimators (BASELINE.json configs 4 and 5; NOT in the reference, which can only
+ * enumerate).  The sampler is the build's own definition, restated here so that the HIP kernels
+ * (csrc/simplex.hip: sample_subset) can be checked draw for draw: splitmix64 counter generator keyed by
+ * (seed, target, sample); k distinct indices in [0, no) by rejection, sorted ascending.
+ * -------------------------------------------------------------------------- */
+static u64 mix64(u64 z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+static void sample_subset(u64 seed, u64 tg, u64 sample, int k, long no, long *idx) {
+    u64 key = mix64(seed ^ mix64(tg * 0xD1342543DE82EF95ull + sample));
+    u64 ctr = 0;
+    for (int p = 0; p < k;) {
+        u64 r = mix64(key + ctr++);
+        long c = (long)(r % (u64)no);
+        int dup = 0;
+        for (int l = 0; l < p; ++l) dup |= (idx[l] == c);
+        if (!dup) idx[p++] = c;
+    }
+    for (int a = 1; a < k; ++a) {
+        long v = idx[a];
+        int b = a - 1;
+        while (b >= 0 && idx[b] > v) { idx[b + 1] = idx[b]; --b; }
+        idx[b + 1] = v;
+    }
+}
+
+/* P is n x T x d (T = 1: point cloud).  out[q] = sum over `samples` sampled (d+1)-subsets of the others of
+ * c (relax) or [c == T] (strict), c = #timepoints where the target lies in the subset's simplex. */
+int oracle_simplex_sampled(const double *P, long n, long T, int d, const long *targets, long m, int relax,
+                           double tol, long samples, u64 seed, i64 *out) {
+    int k = d + 1;
+    if (k > SMAX || n - 1 < k) return -1;
+#pragma omp parallel for schedule(dynamic, 1)
+    for (long q = 0; q < m; ++q) {
+        long tg = targets[q];
+        i64 S = 0;
+        long idx[SMAX];
+        double pts[SMAX * SMAX];
+        for (long s = 0; s < samples; ++s) {
+            sample_subset(seed, (u64)tg, (u64)s, k, n - 1, idx);
+            long cnt = 0;
+            for (long t = 0; t < T; ++t) {
+                for (int c = 0; c < k; ++c) {
+                    long src = idx[c] < tg ? idx[c] : idx[c] + 1;
+                    memcpy(pts + c * d, P + (src * T + t) * d, sizeof(double) * d);
+                }
+                cnt += oracle_point_in_hull(pts, k, d, P + (tg * T + t) * d, tol) > 0;
+            }
+            S += (relax || T == 1) ? cnt : (cnt / T);
+        }
+        out[q] = S;
+    }
+    return 0;
+}
+
+/* --------------------------------------------------------------------------
  * P3  _L1_depth                                        _pointcloud.py:125-150
  *   e = sum_{y != x} (y - x)/||x - y||  (:145-146, in index order);
  *   depth = 1 - ||e|| / n  (:148,150), n includes x.  Coincident points: 0/0=NaN.

@@ -243,6 +243,26 @@ def test_simplex_vs_oracle(eng, oracle):
         assert (eng.multi_simplex_counts(C, None, relax) == oracle.multi_simplex_counts(C, None, relax)).all()
 
 
+def test_sampled_simplex_estimators(eng, oracle):
+    """Configs 4/5 use the build's seeded subset sampler: kernel == CPU restatement draw for draw, and the
+    estimate converges to the exhaustive count."""
+    rng = np.random.default_rng(8)
+    P = rng.normal(size=(40, 3))
+    for seed in (0, 12345):
+        got = eng.pointcloud_simplex_counts(P, samples=500, seed=seed)
+        assert (got == oracle.simplex_sampled(P, samples=500, seed=seed)).all()
+    C = rng.normal(size=(12, 6, 2)).cumsum(axis=1)
+    for relax in (True, False):
+        got = eng.multi_simplex_counts(C, [0, 5, 11], relax=relax, samples=300, seed=7)
+        assert (got == oracle.simplex_sampled(C, [0, 5, 11], relax=relax, samples=300, seed=7)).all()
+    # statistical agreement with the exhaustive depth: P(contain) estimated from 20000 draws
+    Q = rng.normal(size=(25, 2))
+    import math
+    exact = oracle.pointcloud_simplex_counts(Q) / math.comb(24, 3)
+    est = eng.pointcloud_simplex_counts(Q, samples=20000, seed=3) / 20000.0
+    assert np.max(np.abs(est - exact)) < 0.02
+
+
 # ---------------------------------------------------------------- BASELINE.json sizes: size-independent properties
 def test_config2_scale_properties(eng, oracle):
     """10 000 curves x 1 000 timepoints (BASELINE.json configs[1]): the two HIP formulations agree on
