@@ -1,4 +1,5 @@
-// mbd_rank.hip -- K1+K2, rank formulation: the same integers as the pairwise kernel in
+// mbd_rank.hip -- K1+K2, rank formulation, FIRST GENERATION (kept as an independent cross-check,
+// SD_RANK_IMPL=1; the default path is mbd_rank_ab.hip): the same integers as the pairwise kernel in
 // O(n T log n).
 //
 // For one timepoint the counts A (others strictly above) and B (strictly below) of
@@ -262,17 +263,6 @@ static int rank_grid(i64 T) {
     return (int)g;
 }
 
-bool mbd_rank_supported(i64 T, i64 n, int J) {
-    (void)T;
-    return n >= 2 && n <= 16384 && (J == 2 || J == 3);
-}
-
-size_t mbd_rank_workspace_bytes(i64 T, i64 n, int J) {
-    if (!mbd_rank_supported(T, n, J)) return 0;
-    i64 g = T < RK_MAXG ? T : RK_MAXG;
-    return (size_t)g * (J - 1) * n * 8;
-}
-
 template <int NT, int E, int J, int PH = 3>
 static int launch_rank_cfg(const double *Y, i64 T, i64 n, u64 *partial, int G, hipStream_t s) {
     using C = RankCfg<NT, E>;
@@ -302,25 +292,9 @@ static int launch_rank_j(const double *Y, i64 T, i64 n, u64 *partial, int G, hip
     return launch_rank_cfg<1024, 16, J>(Y, T, n, partial, G, s);
 }
 
-void launch_rank_reduce(const u64 *partial, int G, i64 n, int jc, const i64 *targets, i64 tbegin, i64 m, u64 *out,
-                        hipStream_t s) {
-    hipLaunchKernelGGL(rank_reduce_kernel, dim3((unsigned)((m + 63) / 64)), dim3(1024), 0, s, partial, G, n, jc,
-                       targets, tbegin, m, out);
-}
-
-int rank_grid_for(i64 T) { return rank_grid(T); }
-
-int launch_mbd_rank2(const double *Y, i64 T, i64 n, const i64 *targets, i64 tbegin, i64 m, int J,
-                     u64 *out, void *ws, size_t ws_bytes, hipStream_t s);
-
-int launch_mbd_rank(const double *Y, i64 T, i64 n, const i64 *targets, i64 tbegin, i64 m, int J,
-                    u64 *out, void *ws, size_t ws_bytes, hipStream_t s) {
-    if (!mbd_rank_supported(T, n, J)) return fail(SD_ERR_UNSUPPORTED, "rank kernel covers 2 <= n <= 16384, J in {2,3}");
-    {
-        // SD_RANK_IMPL=1 selects the first-generation kernel (full keys + search) for A/B timing and cross-checks
-        const char *impl = getenv("SD_RANK_IMPL");
-        if (!(impl && atoi(impl) == 1)) return launch_mbd_rank2(Y, T, n, targets, tbegin, m, J, out, ws, ws_bytes, s);
-    }
+// first-generation rank kernel, selectable with SD_RANK_IMPL=1 (J <= 3) as an independent cross-check
+int launch_mbd_rank_v1(const double *Y, i64 T, i64 n, const i64 *targets, i64 tbegin, i64 m, int J,
+                       u64 *out, void *ws, size_t ws_bytes, hipStream_t s) {
     int G = rank_grid(T);
     size_t need = (size_t)G * (J - 1) * n * 8;
     if (!ws || ws_bytes < need) return fail(SD_ERR_WORKSPACE, "rank workspace too small");

@@ -30,8 +30,6 @@ def test_golden_univariate_api(name, algo):
     call = fx["call"]
     if not call["relax"] and algo == "rank":
         pytest.skip("algo only selects the relax=True kernel")
-    if call["relax"] and algo == "rank" and call["J"] > 3:
-        pytest.skip("rank kernel covers J <= 3")
     df = frame_df(fx["input"])
     got = FunctionalDepth([df], to_compute=call["to_compute"], J=call["J"], relax=call["relax"],
                           containment=call["containment"], algo=algo)
@@ -180,12 +178,32 @@ def test_mbd_counts_range_vs_oracle(eng, oracle):
             assert (eng.mbd_counts_range(X, lo, m, 2, algo=algo) == want).all()
 
 
-def test_mbd_high_J_pairwise(eng, oracle):
+def test_mbd_high_J(eng, oracle):
     rng = np.random.default_rng(5)
     X = rng.integers(0, 9, size=(12, 40)).astype(float)
     X[2, 3] = np.nan
     for J in (4, 5, 8):
-        assert (eng.mbd_counts(X, None, J, algo="pairwise") == oracle.mbd_counts(X, None, J)).all()
+        for algo in ("pairwise", "rank"):
+            assert (eng.mbd_counts(X, None, J, algo=algo) == oracle.mbd_counts(X, None, J)).all()
+
+
+def test_rank_implementations_cross_check(eng, oracle, monkeypatch):
+    """The three rank implementations (packed keys + deferred rows, search for every row, first generation)
+    are independent pieces of code: they must agree with each other and with the oracle on ties, near-ties
+    (values equal above the index field of the packed key) and specials."""
+    rng = np.random.default_rng(99)
+    base = np.round(rng.normal(size=(9, 3000)).cumsum(axis=0), 1)
+    near = 1.0 + rng.integers(0, 50, size=(9, 3000)) * 2.0 ** -50           # distinct values, identical high bits
+    big = 1.7e9 + rng.normal(size=(9, 3000)) * 1e-3                         # timestamps-like magnitudes
+    tiny = rng.integers(-3, 4, size=(9, 3000)) * 5e-324                      # denormals around zero
+    cont = rng.normal(size=(9, 3000))
+    cont[4, :7] = [np.inf, -np.inf, np.nan, 0.0, -0.0, 1.79e308, -1.79e308]
+    for X in (base, near, big, tiny, cont):
+        want = oracle.mbd_counts(X, None, 2)
+        for impl in ("3", "2", "1"):
+            monkeypatch.setenv("SD_RANK_IMPL", impl)
+            assert (eng.mbd_counts(X, None, 2, algo="rank") == want).all(), impl
+    monkeypatch.delenv("SD_RANK_IMPL")
 
 
 def test_above_below_vs_oracle(eng, oracle):
