@@ -86,7 +86,6 @@ def main():
     X_host = rng.normal(size=(T, n_loc)).cumsum(axis=0)
     X_loc = torch.from_numpy(X_host).to(dev)                       # [T, n_loc] time-major, resident in HBM
     X_all = X_loc
-    targets = torch.arange(rank * n_loc, (rank + 1) * n_loc, dtype=torch.int64, device=dev)
     out = torch.empty((n_loc, J - 1), dtype=torch.int64, device=dev)
     algo = ALGOS[args.algo]
     wsb = 0 if use_dist else lib.sd_mbd_workspace_bytes(T, n, n, 1, n_loc, J, algo)
@@ -103,8 +102,8 @@ def main():
             # (all-gather) for --algo pairwise
             out.copy_(sharded_mbd_counts(X_loc, J=J, algo=args.algo, sizes=sizes))
         else:
-            check(lib.sd_mbd_counts(X_all.data_ptr(), T, n, n, 1, targets.data_ptr(), n_loc, J, algo,
-                                    out.data_ptr(), ws.data_ptr(), wsb, stream.cuda_stream))
+            check(lib.sd_mbd_counts_range(X_all.data_ptr(), T, n, n, 1, rank * n_loc, n_loc, J, algo,
+                                          out.data_ptr(), ws.data_ptr(), wsb, stream.cuda_stream))
 
     def barrier():
         if use_dist:
