@@ -54,6 +54,9 @@ def main():
     ap.add_argument("--algo", default="auto", choices=["auto", "pairwise", "rank"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-targets", type=int, default=4096)
+    ap.add_argument("--variant", default="walk", choices=["walk", "ties"],
+                    help="walk: continuous random walks (headline); ties: the same rounded to 1 decimal with 1 %% "
+                         "duplicated curves (SURVEY.md 8(d) config 2 variant)")
     ap.add_argument("--force-dist", action="store_true",
                     help="run the torch.distributed path even at world size 1 (exercises RCCL on one GPU)")
     args = ap.parse_args()
@@ -84,6 +87,10 @@ def main():
     # synthetic curves: random walks (SURVEY.md 8(d) config 2 recipe), one block per rank
     rng = np.random.default_rng(1234 + rank)
     X_host = rng.normal(size=(T, n_loc)).cumsum(axis=0)
+    if args.variant == "ties":
+        X_host = np.round(X_host, 1)
+        dup = rng.choice(n_loc, size=max(1, n_loc // 100), replace=False)
+        X_host[:, dup] = X_host[:, (dup + 1) % n_loc]
     X_loc = torch.from_numpy(X_host).to(dev)                       # [T, n_loc] time-major, resident in HBM
     X_all = X_loc
     out = torch.empty((n_loc, J - 1), dtype=torch.int64, device=dev)
@@ -142,7 +149,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"MBD J={J}: {n} curves x {T} timepoints (n_loc={n_loc} targets per GPU), fp64 "
-                                   f"random walks, time-major", "algorithm": used,
+                                   f"random walks{' rounded to 0.1 + 1% duplicates' if args.variant == 'ties' else ''}, time-major", "algorithm": used,
                        "parallelism": (f"single GPU" if N == 1 else
                                        (f"targets sharded x{N}, RCCL all-gather of curve blocks" if used == "pairwise" else
                                         f"curves owned x{N}, timepoints sharded for the sort: RCCL all-to-all + reduce-scatter"))},

@@ -236,10 +236,13 @@ __global__ __launch_bounds__(NT) void rank_search_kernel(const double *__restric
                     u32 ab = AB_SPECIAL;
                     if (x == x) {
                         int lo = r2_bound<N, SlotPad<LE>, false, false>(Sm, n_act, x, INF);   // x is in the row
-                        // upper bound: one probe settles it unless x is tied with its successor
-                        int hi = lo + 1;
-                        double nx = (hi < n_act) ? Sm[r2_phys<LE>(hi)] : INF;
-                        if (hi < n_act && nx <= x) hi = r2_bound<N, SlotPad<LE>, true>(Sm, n_act, x, INF);
+                        // upper bound: x sits at lo; gallop over its tie run (1 probe if untied, ~2 log2(run) otherwise)
+                        int hi = lo + 1, step = 1;
+                        while (hi + step <= n_act && Sm[r2_phys<LE>(hi + step - 1)] <= x) { hi += step; step <<= 1; }
+                        while (step > 1) {
+                            step >>= 1;
+                            if (hi + step <= n_act && Sm[r2_phys<LE>(hi + step - 1)] <= x) hi += step;
+                        }
                         // keys <= x within [0, n_act) are real non-NaN values unless x = +inf
                         u32 A = (x == INF) ? 0u : (u32)(n - hi) - nnan;
                         ab = (u32)lo | (A << 16);
