@@ -10,7 +10,7 @@ template <int NT, int E>
 struct R2Cfg {
     static constexpr int N = NT * E;
     static constexpr int LE = (E == 1) ? 0 : (E == 2) ? 1 : (E == 4) ? 2 : (E == 8) ? 3 : (E == 16) ? 4 : 5;
-    static constexpr int LT = (NT == 256) ? 8 : (NT == 512) ? 9 : 10;
+    static constexpr int LT = (NT == 64) ? 6 : (NT == 128) ? 7 : (NT == 256) ? 8 : (NT == 512) ? 9 : 10;
     static constexpr int LN = LE + LT;
     static constexpr int WB = 64 * E;                  // positions owned by one wave in wave-local layouts
     static constexpr int SLOTS = N + (N >> LE);
