@@ -353,3 +353,23 @@ def test_overflow_is_reported_not_wrapped():
     with pytest.raises(StatdepthHipError) as ei:
         engine.mbd_counts(X, [0, 1], J=4, algo="pairwise")
     assert ei.value.code == SD_ERR_OVERFLOW
+
+
+def test_config3_scale_properties(eng, oracle):
+    """100 000 curves x 256 timepoints (BASELINE.json configs[2]) on one GPU: the chunked rank kernels against the
+    pairwise kernel on a target subset and the oracle on a few targets, plus the no-tie rank-sum invariant."""
+    import torch
+    T, n = 256, 100000
+    g = torch.Generator(device="cuda").manual_seed(1235)
+    X = torch.randn(T, n, dtype=torch.float64, device="cuda", generator=g).cumsum(0)
+    full = eng.mbd_counts(X, None, 2, algo="rank")[:, 0]
+    tg = np.arange(5, n, 997)
+    assert (eng.mbd_counts(X, tg, 2, algo="pairwise")[:, 0] == full[tg]).all()
+    Xh = X.cpu().numpy()
+    tg2 = np.array([0, 16383, 16384, 50000, 99999])
+    assert (oracle.mbd_counts(Xh, tg2, 2)[:, 0] == full[tg2]).all()
+    expect = T * (n * ((n - 1) * (n - 2) // 2) - 2 * sum(k * (k - 1) // 2 for k in range(n)))
+    assert int(full.astype(object).sum()) == expect
+    # contiguous target block (what a rank of the sharded path asks for)
+    blk = eng.mbd_counts_range(X, 37500, 12500, 2)[:, 0]
+    assert (blk == full[37500:50000]).all()
