@@ -10,7 +10,7 @@ from typing import List
 
 import pandas as pd
 
-from .abstract import AbstractDepth
+from abc import ABC, abstractmethod
 from .calculations._functional import _functionaldepth, _samplefunctionaldepth
 from .calculations._helper import DepthDegeneracy   # noqa: F401
 from .calculations._pointcloud import _pointwisedepth, _samplepointwisedepth
@@ -18,38 +18,55 @@ from .calculations._pointcloud import _pointwisedepth, _samplepointwisedepth
 __all__ = ['FunctionalDepth', 'PointcloudDepth']
 
 
+class AbstractDepth(ABC):
+    """What every depth result can do (reference: statdepth/depth/abstract.py:3-18)."""
+
+    @abstractmethod
+    def ordered(self, ascending=False): ...
+
+    @abstractmethod
+    def deepest(self, n=1): ...
+
+    @abstractmethod
+    def outlying(self, n=1): ...
+
+
 class _FunctionalDepthSeries(AbstractDepth, pd.Series):
-    """Depth values as a Series that also remembers its data (:14-65)."""
+    """The depth values as a Series that also remembers the data they were computed from (:14-65).
+
+    Ordering conventions of the reference are kept: `ordered()` caches the FIRST ordering it is asked for
+    (:25-27), `deepest`/`outlying` read the head/tail of a descending ordering (:29-46), `quartile` ignores
+    its argument and returns the lower half (:55-56).  Ties are ordered by `Series.sort_values`'s default
+    sort, like the reference.
+    """
 
     def __init__(self, df: pd.DataFrame, depths: pd.Series):
         super().__init__(data=depths)
-        # plain attributes, like the reference: a reference to the frame, not a copy (:19)
-        object.__setattr__(self, '_orig_data', df)
-        object.__setattr__(self, '_depths', depths)
-        object.__setattr__(self, '_ordered_depths', None)
+        # plain attributes (bypassing pandas' attribute machinery); a reference to the frame, not a copy (:19)
+        for name, value in (('_orig_data', df), ('_depths', depths), ('_ordered_depths', None)):
+            object.__setattr__(self, name, value)
+
+    def _ranking(self, ascending=False) -> pd.Series:
+        cached = self._ordered_depths
+        if cached is None:
+            cached = self._depths.sort_values(ascending=ascending)
+            object.__setattr__(self, '_ordered_depths', cached)
+        return cached
+
+    @staticmethod
+    def _slice(ranked: pd.Series, sel) -> pd.Series:
+        return pd.Series(index=list(ranked.index[sel]), data=list(ranked.values[sel]))
 
     def ordered(self, ascending=False) -> pd.Series:
-        '''Sort by depth, deepest first (:23-27).'''
-        if self._ordered_depths is None:
-            object.__setattr__(self, '_ordered_depths', self._depths.sort_values(ascending=ascending))
-        return self._ordered_depths
+        return self._ranking(ascending)
 
     def deepest(self, n=1) -> pd.Series:
-        '''The n deepest items (:29-37).'''
-        if self._ordered_depths is None:
-            object.__setattr__(self, '_ordered_depths', self._depths.sort_values(ascending=False))
-        if n == 1:
-            return pd.Series(index=[list(self._ordered_depths.index)[0]], data=[self._ordered_depths.values[0]])
-        return pd.Series(index=self._ordered_depths.index[0: n], data=self._ordered_depths.values[0: n])
+        return self._slice(self._ranking(False), slice(0, n))
 
     def outlying(self, n=1) -> pd.Series:
-        '''The n most outlying items (:39-46).'''
-        if self._ordered_depths is None:
-            object.__setattr__(self, '_ordered_depths', self._depths.sort_values(ascending=False))
-        if n == 1:
-            return pd.Series(index=[list(self._ordered_depths.index)[-1]], data=[self._ordered_depths.values[-1]])
-        return pd.Series(index=self._ordered_depths.index[-n:], data=self._ordered_depths.values[-n:])
+        return self._slice(self._ranking(False), slice(-n, None))
 
+    # aliases (:48-65)
     def sorted(self, ascending=False):
         return self.ordered(ascending=ascending)
 
@@ -57,17 +74,16 @@ class _FunctionalDepthSeries(AbstractDepth, pd.Series):
         return self.deepest(n=1)
 
     def quartile(self, ratio=0.5):
-        # the reference ignores `ratio` and always takes the lower half (:55-56)
         return self._depths.sort_values().head(int(self._depths.shape[0] * 0.5))
 
     def get_depths(self):
         return self._depths
 
+    def depths(self):
+        return self._depths
+
     def get_data(self):
         return self._orig_data
-
-    def depths(self):
-        return self.get_depths()
 
 
 class _FunctionalDepthUnivariate(_FunctionalDepthSeries):
