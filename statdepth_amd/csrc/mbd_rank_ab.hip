@@ -381,6 +381,10 @@ static int ab_grid(i64 rows, int per_cu = 1) {
 
 static i64 ab_rows_per_batch(i64 T, i64 n) {
     i64 r = ((i64)1 << 30) / (n * 4);       // pair image <= 1 GiB
+    if (const char *e = getenv("SD_RANK_ROWS_PER_BATCH")) {   // tests: force several batches on small inputs
+        i64 v = atoll(e);
+        if (v > 0 && v < r) r = v;
+    }
     if (r < 1) r = 1;
     return r < T ? r : T;
 }

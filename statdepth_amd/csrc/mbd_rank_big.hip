@@ -16,6 +16,8 @@
 // registers over the rows and added to the int64 outputs with one atomic per curve.
 // Replaces the same reference loops as the other K1+K2 kernels (_functional.py:246-251,
 // _containment.py:75-77).
+#include <stdlib.h>
+
 #include "sd_common.h"
 #include "rank_sort.h"
 
@@ -153,6 +155,10 @@ static inline i64 big_nchunks(i64 n) { return (n + BIG_C - 1) / BIG_C; }
 static i64 big_rows_per_batch(i64 T, i64 n) {
     i64 sstride = big_nchunks(n) * BIG_C;
     i64 r = ((i64)1 << 30) / (sstride * 8);
+    if (const char *e = getenv("SD_RANK_ROWS_PER_BATCH")) {   // tests: force several batches on small inputs
+        i64 v = atoll(e);
+        if (v > 0 && v < r) r = v;
+    }
     if (r < 1) r = 1;
     if (r > T) r = T;
     if (r > 65535) r = 65535;

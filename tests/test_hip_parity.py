@@ -373,3 +373,18 @@ def test_config3_scale_properties(eng, oracle):
     # contiguous target block (what a rank of the sharded path asks for)
     blk = eng.mbd_counts_range(X, 37500, 12500, 2)[:, 0]
     assert (blk == full[37500:50000]).all()
+
+
+def test_row_batching(eng, oracle, monkeypatch):
+    """Rows are processed in batches when the pair image / sorted scratch would exceed 1 GiB; force small batches."""
+    rng = np.random.default_rng(77)
+    monkeypatch.setenv("SD_RANK_ROWS_PER_BATCH", "7")
+    X = np.round(rng.normal(size=(40, 700)).cumsum(axis=0), 1)
+    X[11, 5] = np.nan
+    for J in (2, 3):
+        assert (eng.mbd_counts(X, None, J, algo="rank") == oracle.mbd_counts(X, None, J)).all()
+    tg = np.array([3, 699, 0, 350])
+    assert (eng.mbd_counts(X, tg, 2, algo="rank") == oracle.mbd_counts(X, tg, 2)).all()
+    monkeypatch.setenv("SD_RANK_ROWS_PER_BATCH", "2")
+    Xb = rng.normal(size=(5, 17000))
+    assert (eng.mbd_counts(Xb, None, 2, algo="rank") == oracle.mbd_counts(Xb, None, 2)).all()
