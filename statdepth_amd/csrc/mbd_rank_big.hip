@@ -1,21 +1,29 @@
 // mbd_rank_big.hip -- K1+K2 rank formulation for rows that do not fit one CU's LDS
-// (16 384 < n < 2^31 curves; BASELINE.json config 3 and the north-star stretch case).
+// (16 384 < n < 2^31 curves; BASELINE.json config 3, the north-star stretch case, and every multi-GPU run).
 //
-// A row of n curves is cut into chunks of C = 16 384 keys.
-//   kernel A  chunk_sort_kernel:   one workgroup sorts one (row, chunk) in LDS (rank_sort.h,
-//             NaN -> +inf and counted per row) and writes the sorted chunk to a scratch image
-//             in HBM (rows x chunks x C fp64; config 3: 235 MB of the 288 GB).
-//   kernel B  chunk_search_kernel: a persistent workgroup owns one chunk of *curves* and a
-//             strided set of rows; per row it streams every sorted chunk of that row through
-//             LDS (coalesced 128 KiB copies) and every thread adds, for its own 16 curves,
-//             lower_bound / upper_bound within that chunk.  Summed over the chunks these are
-//             exactly B (others strictly below) and n_valid - A (A strictly above), so the
-//             totals are the integers of the other formulations.
-// Work per row: n/C sorts + (n/C)^2 chunk searches, i.e. O(n log C + n^2 log C / C) instead
-// of the pairwise kernel's O(n^2) -- ~300x less work at n = 10^5.  Totals are accumulated in
-// registers over the rows and added to the int64 outputs with one atomic per curve.
-// Replaces the same reference loops as the other K1+K2 kernels (_functional.py:246-251,
-// _containment.py:75-77).
+// Same integers as the other K1+K2 kernels (reference loops _functional.py:246-251, _containment.py:75-77).
+// Per row the ranks B (others strictly below) and A (strictly above) of every curve are written as a
+// (uint32, uint32) pair image; rank_accumulate2_kernel folds C(v,j) - C(A,j) - C(B,j) over the rows.
+//
+// Route 1 (default): sample-partition into value buckets, so that no rank needs another bucket's keys.
+//   S  bucket_splitters_kernel  one workgroup per row sorts a 4 096-element strided sample in LDS and
+//                               publishes NB-1 splitters (NB ~ n / 5 500 buckets of capacity 8 192).
+//   P  bucket_partition_kernel  every element finds its bucket (binary search over the splitters in LDS;
+//                               equal values always land together), slots are handed out with one LDS
+//                               atomic per element and one global atomic per (workgroup, bucket); values
+//                               and curve ids are scattered into the bucket arrays.  NaNs never enter a
+//                               bucket: they are counted and marked in the pair image right here.
+//   A  bucket_packed_kernel     one workgroup per (row, bucket): packed-key sort (slot index in the low
+//                               mantissa bits, rank_sort.h), rank = bucket base + position, handed to the
+//                               slot's owner through LDS and scattered to the curve's pair.  A bucket with
+//                               ties or near-ties is flagged for
+//   B  bucket_search_kernel     sort of the plain values + binary search inside the bucket (exact for ties).
+// Route 2 (overflow fallback, SD_BIG_IMPL=1 forces it): a row whose partition overflowed a bucket (a
+//   quarter of the row tied on one value, say) is cut into chunks of 16 384 keys in curve order:
+//   chunk_sort_kernel sorts every chunk, chunk_search_kernel streams every sorted chunk of the row through
+//   LDS and sums lower/upper bounds per chunk: O((n/C)^2) chunk searches per row instead of none.
+// Work per row, route 1: one streaming pass + n/5 500 LDS sorts; config 3 (10^5 x 256) on one MI355X:
+// see DESIGN.md.
 #include <stdlib.h>
 
 #include "sd_common.h"
@@ -23,18 +31,25 @@
 
 namespace sd {
 
+struct AB2 { u32 B, A; };
+constexpr u32 AB2_NAN = 0xFFFFFFFFu;           // B field: the curve is NaN at this timepoint
+
+// =====================================================================================================
+// route 2: chunks in curve order
+// =====================================================================================================
 constexpr int BIG_NT = 1024, BIG_E = 16;
 constexpr int BIG_C = BIG_NT * BIG_E;          // 16384 keys per chunk
 using BigCfg = R2Cfg<BIG_NT, BIG_E>;
 
-// grid = (nchunks, rows_in_batch)
+// grid = (nchunks, rows_in_batch); rowflag != nullptr: only rows with a non-zero flag
 __global__ __launch_bounds__(BIG_NT) void chunk_sort_kernel(const double *__restrict__ Y, i64 n, i64 row0,
                                                             double *__restrict__ sorted, i64 sstride,
-                                                            u32 *__restrict__ nanrow) {
+                                                            u32 *__restrict__ nanrow, const u32 *__restrict__ rowflag) {
     constexpr int E = BIG_E, WB = BigCfg::WB;
     extern __shared__ double Sm[];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const i64 c = blockIdx.x, rb = blockIdx.y;
+    if (rowflag && !rowflag[rb]) return;
     const i64 base = c * BIG_C;
     const int nc = (int)((n - base) < BIG_C ? (n - base) : BIG_C);
     const int n_act = ((nc + WB - 1) / WB) * WB;
@@ -65,28 +80,22 @@ __global__ __launch_bounds__(BIG_NT) void chunk_sort_kernel(const double *__rest
 }
 
 // grid = G persistent workgroups; workgroup g owns curve chunk g % nchunks and rows g / nchunks + k * (G / nchunks)
-template <int J>
 __global__ __launch_bounds__(BIG_NT) void chunk_search_kernel(const double *__restrict__ Y, i64 n, i64 row0,
                                                               i64 rows, const double *__restrict__ sorted,
                                                               i64 sstride, const u32 *__restrict__ nanrow,
-                                                              int nchunks, int qc0, int nqc,
-                                                              u64 *__restrict__ totals) {
+                                                              int nchunks, const u32 *__restrict__ rowflag,
+                                                              AB2 *__restrict__ ab) {
     constexpr int E = BIG_E, WB = BigCfg::WB, N = BIG_C;
     extern __shared__ double Sm[];
     const int t = threadIdx.x;
-    // only the curve chunks [qc0, qc0 + nqc) hold targets
-    const int qc = qc0 + (int)(blockIdx.x % nqc);
-    const int rgroups = gridDim.x / nqc;
+    const int qc = (int)(blockIdx.x % nchunks);
+    const int rgroups = gridDim.x / nchunks;
     const i64 qbase = (i64)qc * BIG_C;
     const int nq = (int)((n - qbase) < BIG_C ? (n - qbase) : BIG_C);
     const double INF = __builtin_huge_val();
-    u64 acc[E][JMAX - 1];
-#pragma unroll
-    for (int e = 0; e < E; ++e)
-#pragma unroll
-        for (int j = 0; j < J - 1; ++j) acc[e][j] = 0;
 
-    for (i64 rb = blockIdx.x / nqc; rb < rows; rb += rgroups) {
+    for (i64 rb = blockIdx.x / nchunks; rb < rows; rb += rgroups) {
+        if (rowflag && !rowflag[rb]) continue;
         const double *xp = Y + (row0 + rb) * n + qbase + t;
         double x[E];
         u32 lo[E], hi[E];
@@ -119,42 +128,369 @@ __global__ __launch_bounds__(BIG_NT) void chunk_search_kernel(const double *__re
             }
         }
         const u32 nnan = nanrow[rb];
+        AB2 *dst = ab + rb * n + qbase + t;
 #pragma unroll
         for (int e = 0; e < E; ++e) {
-            if (t + e * BIG_NT < nq && x[e] == x[e]) {
-                u32 B = lo[e];
-                u32 A = (x[e] == INF) ? 0u : (u32)(n - hi[e]) - nnan;
-                band_counts_add<J>(A, B, nnan, (u64)(n - 1), acc[e]);
+            if (t + e * BIG_NT < nq) {
+                AB2 v;
+                if (x[e] == x[e]) {
+                    v.B = lo[e];
+                    v.A = (x[e] == INF) ? 0u : (u32)(n - hi[e]) - nnan;
+                } else {
+                    v.B = AB2_NAN;
+                    v.A = 0;
+                }
+                dst[e * BIG_NT] = v;
             }
         }
     }
+}
+
+// =====================================================================================================
+// route 1: value buckets
+// =====================================================================================================
+constexpr int BK_NT = 512, BK_E = 16;
+constexpr int BK_C = BK_NT * BK_E;             // bucket capacity 8192
+constexpr int BK_FILL = 5500;                  // target mean fill
+constexpr int BK_SS = 4096;                    // sample size (sorted by one 256-thread workgroup)
+constexpr int BK_MAXNB = 1024;
+using BkCfg = R2Cfg<BK_NT, BK_E>;
+using SsCfg = R2Cfg<256, 16>;
+
+static inline int bucket_count(i64 n) {
+    i64 nb = (n + BK_FILL - 1) / BK_FILL;
+    if (nb < 2) nb = 2;
+    return (int)nb;
+}
+
+// S: grid = rows; spl[r][0..NB-2] ascending
+__global__ __launch_bounds__(256) void bucket_splitters_kernel(const double *__restrict__ Y, i64 n, i64 row0, int NB,
+                                                               double *__restrict__ spl) {
+    constexpr int E = 16, LE = SsCfg::LE;
+    extern __shared__ double Sm[];
+    const int t = threadIdx.x;
+    const i64 rb = blockIdx.x;
+    const double *row = Y + (row0 + rb) * n;
+    const double INF = __builtin_huge_val();
+    double k[E];
 #pragma unroll
     for (int e = 0; e < E; ++e) {
-        i64 i = qbase + t + e * BIG_NT;
-        if (t + e * BIG_NT < nq) {
+        const i64 s = (i64)t * E + e;                       // sample index, any assignment of samples to slots works
+        double v = row[(s * n) / BK_SS];
+        k[e] = (v == v) ? v : INF;
+    }
+    R2Sorter<256, 16>::sort(k, Sm, t, BK_SS, true, INF);
+    double *Sw = Sm + r2_base<0, LE>(t);
 #pragma unroll
-            for (int j = 0; j < J - 1; ++j)
-                if (acc[e][j]) atomicAdd(&totals[(size_t)j * n + i], acc[e][j]);
-        }
+    for (int e = 0; e < E; ++e) Sw[r2_off<0, LE>(e)] = k[e];
+    __syncthreads();
+    for (int b = t; b < NB - 1; b += 256) {
+        const int q = (int)(((i64)(b + 1) * BK_SS) / NB);
+        spl[rb * (NB - 1) + b] = Sm[r2_phys<LE>(q)];
     }
 }
 
-// out[q*(J-1)+j] = totals[j][targets[q]]
-__global__ __launch_bounds__(256) void big_gather_kernel(const u64 *__restrict__ totals, i64 n, int jc,
-                                                         const i64 *__restrict__ targets, i64 tbegin, i64 m,
-                                                         u64 *__restrict__ out) {
-    i64 q = (i64)blockIdx.x * 256 + threadIdx.x;
-    if (q >= m) return;
-    i64 i = targets ? targets[q] : tbegin + q;
-    for (int j = 0; j < jc; ++j) out[q * jc + j] = totals[(size_t)j * n + i];
+// P: grid = (ceil(n / 16384), rows)
+__global__ __launch_bounds__(1024) void bucket_partition_kernel(const double *__restrict__ Y, i64 n, i64 row0, int NB,
+                                                                const double *__restrict__ spl,
+                                                                u32 *__restrict__ bcnt, u32 *__restrict__ nnanrow,
+                                                                u32 *__restrict__ ovf, double *__restrict__ bval,
+                                                                u32 *__restrict__ bidx, AB2 *__restrict__ ab) {
+    __shared__ double s_spl[BK_MAXNB];
+    __shared__ u32 s_hist[BK_MAXNB];
+    __shared__ u32 s_base[BK_MAXNB];
+    const int t = threadIdx.x;
+    const i64 rb = blockIdx.y;
+    const i64 base = (i64)blockIdx.x * 16384;
+    for (int b = t; b < NB; b += 1024) {
+        if (b < NB - 1) s_spl[b] = spl[rb * (NB - 1) + b];
+        s_hist[b] = 0;
+    }
+    __syncthreads();
+    const double *row = Y + (row0 + rb) * n;
+    double x[16];
+    u32 bk[16], off[16];
+    u32 mynan = 0;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const i64 i = base + t + e * 1024;
+        x[e] = (i < n) ? row[i] : 0.0;
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const i64 i = base + t + e * 1024;
+        bk[e] = 0xFFFFFFFFu;
+        if (i < n) {
+            if (x[e] == x[e]) {
+                // bucket = number of splitters < x (equal values always share a bucket)
+                int lo = 0, hi = NB - 1;
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    if (s_spl[mid] < x[e]) lo = mid + 1;
+                    else hi = mid;
+                }
+                bk[e] = (u32)lo;
+                off[e] = atomicAdd(&s_hist[lo], 1u);
+            } else {
+                ++mynan;
+                AB2 v;
+                v.B = AB2_NAN;
+                v.A = 0;
+                ab[rb * n + i] = v;
+            }
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) mynan += __shfl_down(mynan, o);
+    if ((t & 63) == 0 && mynan) atomicAdd(&nnanrow[rb], mynan);
+    __syncthreads();
+    for (int b = t; b < NB; b += 1024) s_base[b] = s_hist[b] ? atomicAdd(&bcnt[rb * NB + b], s_hist[b]) : 0u;
+    __syncthreads();
+    bool over = false;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        if (bk[e] != 0xFFFFFFFFu) {
+            const u32 pos = s_base[bk[e]] + off[e];
+            if (pos < (u32)BK_C) {
+                const size_t slot = ((size_t)rb * NB + bk[e]) * BK_C + pos;
+                bval[slot] = x[e];
+                bidx[slot] = (u32)(base + t + e * 1024);
+            } else {
+                over = true;
+            }
+        }
+    }
+    if (over) ovf[rb] = 1u;
 }
 
+template <int NT, int E>
+struct BkKeys {
+    using C = R2Cfg<NT, E>;
+    static constexpr int LN = C::LN;
+    static constexpr u64 MASK = (u64)C::N - 1;
+    static constexpr u64 TOPM = ((0xFFFFFFFFFFFFFull >> LN) << LN);
+    static constexpr u64 H3 = (0x7FEull << 52) | TOPM;         // padding class (largest)
+    static constexpr u64 H1 = H3 - ((u64)2 << LN);             // +inf class (H3 - 1 class stays unused here: no NaN)
+    static constexpr u64 SIGN = 0x8000000000000000ull;
+    static constexpr u64 LOW = (u64)1 << LN;
+};
+
+__device__ __forceinline__ u64 bk_bits(double v) { return (u64)__double_as_longlong(v); }
+__device__ __forceinline__ double bk_dbl(u64 b) { return __longlong_as_double((long long)b); }
+
+// A: grid = (NB, rows)
+__global__ __launch_bounds__(BK_NT) void bucket_packed_kernel(i64 n, int NB, const u32 *__restrict__ bcnt,
+                                                              const u32 *__restrict__ nnanrow,
+                                                              const u32 *__restrict__ ovf,
+                                                              const double *__restrict__ bval,
+                                                              const u32 *__restrict__ bidx, u32 *__restrict__ bflag,
+                                                              AB2 *__restrict__ ab) {
+    using C = BkCfg;
+    using K = BkKeys<BK_NT, BK_E>;
+    constexpr int E = BK_E, NT = BK_NT, LN = C::LN, WB = C::WB;
+    constexpr u64 MASK = K::MASK, CLS_PAD = K::H3 >> LN;
+    extern __shared__ double Sm[];
+    double *firstkey = Sm + C::SLOTS;
+    __shared__ u32 s_basecnt;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int b = blockIdx.x;
+    const i64 rb = blockIdx.y;
+    if (ovf[rb]) return;
+    const int cnt = (int)bcnt[rb * NB + b];
+    if (cnt == 0) return;
+    if (t == 0) {
+        u32 s = 0;
+        for (int q = 0; q < b; ++q) s += bcnt[rb * NB + q];
+        s_basecnt = s;
+    }
+    const int n_act = ((cnt + WB - 1) / WB) * WB;
+    const bool wreal = wave * WB < n_act;
+    const double INF = __builtin_huge_val();
+    const double MAXK = bk_dbl(K::H3 | MASK);
+    const size_t slot0 = ((size_t)rb * NB + b) * BK_C;
+    const int i0 = wave * WB + lane;
+    double k[E];
+    int forcefull = 0;
+    if (wreal) {
+        const double *rp = bval + slot0 + i0;
+#pragma unroll
+        for (int e = 0; e < E; ++e) k[e] = (i0 + e * 64 < cnt) ? rp[e * 64] : INF;
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const int j = i0 + e * 64;
+            const u64 bits = bk_bits(k[e]);
+            const u64 a = bits & ~K::SIGN;
+            u64 kb = bits & ~MASK;
+            if (__builtin_expect((a - K::LOW) >= (K::H1 - K::LOW), 0)) {
+                if (a == 0x7FF0000000000000ull) kb = (bits & K::SIGN) ? (K::SIGN | K::H3) : K::H1;
+                else if (a == 0) kb = 0;
+                else forcefull |= (j < cnt);
+            }
+            kb = (j < cnt) ? kb : K::H3;
+            k[e] = bk_dbl(kb | (u64)j);
+        }
+    }
+    R2Sorter<NT, E>::sort(k, Sm, t, n_act, wreal, MAXK);
+    if (wreal) firstkey[t] = k[0];
+    __syncthreads();
+    int anytie = 0;
+    if (wreal) {
+        u64 nextb = ~0ull;
+        if ((t + 1) * E < n_act) nextb = bk_bits(firstkey[t + 1]);
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const u64 c0 = bk_bits(k[e]) >> LN;
+            const u64 c1 = ((e < E - 1) ? bk_bits(k[e + 1]) : nextb) >> LN;
+            anytie |= (c0 == c1) & (c0 != CLS_PAD);
+        }
+    }
+    if (__syncthreads_or(anytie | forcefull)) {
+        if (t == 0) bflag[rb * NB + b] = 1u;
+        return;
+    }
+    u32 *R = reinterpret_cast<u32 *>(Sm);
+    if (wreal) {
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const int j = (int)(bk_bits(k[e]) & MASK);
+            if (j < cnt) R[j] = (u32)(t * E + e);
+        }
+    }
+    __syncthreads();
+    const u32 base = s_basecnt;
+    const u32 nreal = (u32)n - nnanrow[rb];
+    for (int j = t; j < cnt; j += NT) {
+        AB2 v;
+        v.B = base + R[j];
+        v.A = nreal - 1u - v.B;
+        ab[rb * n + bidx[slot0 + j]] = v;
+    }
+}
+
+// B: grid = (NB, rows), flagged buckets only
+__global__ __launch_bounds__(BK_NT) void bucket_search_kernel(i64 n, int NB, const u32 *__restrict__ bcnt,
+                                                              const u32 *__restrict__ nnanrow,
+                                                              const u32 *__restrict__ bflag,
+                                                              const double *__restrict__ bval,
+                                                              const u32 *__restrict__ bidx, AB2 *__restrict__ ab) {
+    using C = BkCfg;
+    constexpr int E = BK_E, NT = BK_NT, LE = C::LE, WB = C::WB, N = C::N;
+    extern __shared__ double Sm[];
+    __shared__ u32 s_basecnt;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int b = blockIdx.x;
+    const i64 rb = blockIdx.y;
+    if (!bflag[rb * NB + b]) return;
+    const int cnt = (int)bcnt[rb * NB + b];
+    if (t == 0) {
+        u32 s = 0;
+        for (int q = 0; q < b; ++q) s += bcnt[rb * NB + q];
+        s_basecnt = s;
+    }
+    const int n_act = ((cnt + WB - 1) / WB) * WB;
+    const bool wreal = wave * WB < n_act;
+    const double INF = __builtin_huge_val();
+    const size_t slot0 = ((size_t)rb * NB + b) * BK_C;
+    const int i0 = wave * WB + lane;
+    double k[E];
+    if (wreal) {
+        const double *rp = bval + slot0 + i0;
+#pragma unroll
+        for (int e = 0; e < E; ++e) k[e] = (i0 + e * 64 < cnt) ? rp[e * 64] : INF;
+    }
+    R2Sorter<NT, E>::sort(k, Sm, t, n_act, wreal, INF);
+    if (wreal) {
+        double *Sw = Sm + r2_base<0, LE>(t);
+#pragma unroll
+        for (int e = 0; e < E; ++e) Sw[r2_off<0, LE>(e)] = k[e];
+    }
+    __syncthreads();
+    const u32 base = s_basecnt;
+    const u32 nreal = (u32)n - nnanrow[rb];
+    for (int j = t; j < cnt; j += NT) {
+        const double x = bval[slot0 + j];
+        int lo = r2_bound<N, SlotPad<LE>, false, false>(Sm, n_act, x, INF);       // x is in the bucket
+        int hi = lo + 1, step = 1;
+        while (hi + step <= n_act && Sm[r2_phys<LE>(hi + step - 1)] <= x) { hi += step; step <<= 1; }
+        while (step > 1) {
+            step >>= 1;
+            if (hi + step <= n_act && Sm[r2_phys<LE>(hi + step - 1)] <= x) hi += step;
+        }
+        AB2 v;
+        v.B = base + (u32)lo;
+        // values above x: everything real beyond x's tie run (x = +inf: the padding ties with it, nothing is above)
+        v.A = (x == INF) ? 0u : nreal - (base + (u32)hi);
+        ab[rb * n + bidx[slot0 + j]] = v;
+    }
+}
+
+// =====================================================================================================
+// fold the pair image into the totals of the targets: block = 64 targets x 16 row slices
+// =====================================================================================================
+template <int J>
+__global__ __launch_bounds__(1024) void rank_accumulate2_kernel(const AB2 *__restrict__ ab, const u32 *__restrict__ nnan,
+                                                                i64 rows, i64 n, const i64 *__restrict__ targets,
+                                                                i64 tbegin, i64 m, u64 *__restrict__ out, int first) {
+    __shared__ u64 red[16][64];
+    const int x = threadIdx.x & 63, y = threadIdx.x >> 6;
+    const i64 q = (i64)blockIdx.x * 64 + x;
+    const i64 i = (q < m) ? (targets ? targets[q] : tbegin + q) : 0;
+    u64 acc[JMAX - 1];
+#pragma unroll
+    for (int j = 0; j < JMAX - 1; ++j) acc[j] = 0;
+    if (q < m) {
+        i64 r = y;
+        for (; r + 16 * 7 < rows; r += 16 * 8) {
+            AB2 v[8];
+            u32 nn[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                v[u] = ab[(r + 16 * u) * n + i];
+                nn[u] = nnan[r + 16 * u];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (v[u].B != AB2_NAN) band_counts_add<J>(v[u].A, v[u].B, nn[u], (u64)(n - 1), acc);
+        }
+        for (; r < rows; r += 16) {
+            const AB2 v = ab[r * n + i];
+            if (v.B != AB2_NAN) band_counts_add<J>(v.A, v.B, nnan[r], (u64)(n - 1), acc);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < J - 1; ++j) {
+        red[y][x] = acc[j];
+        __syncthreads();
+        if (y == 0 && q < m) {
+            u64 tot = 0;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) tot += red[k][x];
+            if (first) out[q * (J - 1) + j] = tot;
+            else out[q * (J - 1) + j] += tot;
+        }
+        __syncthreads();
+    }
+}
+
+// =====================================================================================================
+// host side
+// =====================================================================================================
 static inline i64 big_nchunks(i64 n) { return (n + BIG_C - 1) / BIG_C; }
 
-// rows per batch so that the sorted image stays below ~1 GiB
-static i64 big_rows_per_batch(i64 T, i64 n) {
-    i64 sstride = big_nchunks(n) * BIG_C;
-    i64 r = ((i64)1 << 30) / (sstride * 8);
+struct BigPlan {
+    i64 nch, sstride, rpb;
+    int NB;
+    size_t off_ab, off_sorted, off_bval, off_bidx, off_spl, off_zero, zero_bytes, total;
+    // zeroed block: bcnt[rpb*NB] | nnanrow[rpb] | ovf[rpb] | bflag[rpb*NB] | nanrow_f[rpb]
+    size_t z_bcnt, z_nnan, z_ovf, z_bflag, z_nanf;
+};
+
+static BigPlan big_plan(i64 T, i64 n) {
+    BigPlan p;
+    p.nch = big_nchunks(n);
+    p.sstride = p.nch * BIG_C;
+    p.NB = bucket_count(n);
+    const size_t per_row = (size_t)n * 8 + (size_t)p.sstride * 8 + (size_t)p.NB * BK_C * 12 + (size_t)p.NB * 16 + 64;
+    i64 r = (i64)(((size_t)3 << 29) / per_row);           // ~1.5 GiB of scratch per batch
     if (const char *e = getenv("SD_RANK_ROWS_PER_BATCH")) {   // tests: force several batches on small inputs
         i64 v = atoll(e);
         if (v > 0 && v < r) r = v;
@@ -162,72 +498,104 @@ static i64 big_rows_per_batch(i64 T, i64 n) {
     if (r < 1) r = 1;
     if (r > T) r = T;
     if (r > 65535) r = 65535;
-    return r;
+    p.rpb = r;
+    size_t o = 0;
+    auto take = [&](size_t bytes) { size_t at = o; o = align_up(o + bytes, 256); return at; };
+    p.off_ab = take((size_t)r * n * 8);
+    p.off_sorted = take((size_t)r * p.sstride * 8);
+    p.off_bval = take((size_t)r * p.NB * BK_C * 8);
+    p.off_bidx = take((size_t)r * p.NB * BK_C * 4);
+    p.off_spl = take((size_t)r * p.NB * 8);
+    p.off_zero = o;
+    size_t z = 0;
+    auto ztake = [&](size_t bytes) { size_t at = z; z = align_up(z + bytes, 256); return at; };
+    p.z_bcnt = ztake((size_t)r * p.NB * 4);
+    p.z_nnan = ztake((size_t)r * 4);
+    p.z_ovf = ztake((size_t)r * 4);
+    p.z_bflag = ztake((size_t)r * p.NB * 4);
+    p.z_nanf = ztake((size_t)r * 4);
+    p.zero_bytes = z;
+    p.total = o + z + 256;
+    return p;
 }
 
 bool mbd_rank_big_supported(i64 T, i64 n, int J) {
     (void)T;
-    return n > 16384 && n < ((i64)1 << 31) && (J == 2 || J == 3) && big_nchunks(n) <= 1024;
+    return n > 16384 && n < ((i64)1 << 31) && J >= 2 && J <= JMAX && big_nchunks(n) <= 1024 &&
+           bucket_count(n) <= BK_MAXNB;
 }
 
 size_t mbd_rank_big_workspace_bytes(i64 T, i64 n, int J) {
     if (!mbd_rank_big_supported(T, n, J)) return 0;
-    i64 rows = big_rows_per_batch(T, n);
-    size_t b = align_up((size_t)rows * big_nchunks(n) * BIG_C * 8, 256);
-    b += align_up((size_t)rows * 4, 256);
-    b += align_up((size_t)(J - 1) * n * 8, 256);
-    return b + 1024;
+    return big_plan(T, n).total + 1024;
 }
 
 int launch_mbd_rank_big(const double *Y, i64 T, i64 n, const i64 *targets, i64 tbegin, i64 m, int J,
                         u64 *out, void *ws, size_t ws_bytes, hipStream_t s) {
-    if (!mbd_rank_big_supported(T, n, J)) return fail(SD_ERR_UNSUPPORTED, "chunked rank kernel covers n > 16384, J in {2,3}");
-    const i64 nch = big_nchunks(n);
-    const i64 sstride = nch * BIG_C;
-    const i64 rpb = big_rows_per_batch(T, n);
-    Carver cv(ws, ws_bytes);
-    double *sorted = (double *)cv.take((size_t)rpb * sstride * 8);
-    u32 *nanrow = (u32 *)cv.take((size_t)rpb * 4);
-    u64 *totals = (u64 *)cv.take((size_t)(J - 1) * n * 8);
-    if (!sorted || !nanrow || !totals) return fail(SD_ERR_WORKSPACE, "chunked rank workspace too small");
-    SD_HIP(hipMemsetAsync(totals, 0, (size_t)(J - 1) * n * 8, s));
+    if (!mbd_rank_big_supported(T, n, J)) return fail(SD_ERR_UNSUPPORTED, "large-n rank kernels cover n > 16384");
+    const BigPlan p = big_plan(T, n);
+    if (!ws || ws_bytes < p.total) return fail(SD_ERR_WORKSPACE, "large-n rank workspace too small");
+    char *w = (char *)(((size_t)ws + 255) / 256 * 256);
+    AB2 *ab = (AB2 *)(w + p.off_ab);
+    double *sorted = (double *)(w + p.off_sorted);
+    double *bval = (double *)(w + p.off_bval);
+    u32 *bidx = (u32 *)(w + p.off_bidx);
+    double *spl = (double *)(w + p.off_spl);
+    char *zb = w + p.off_zero;
+    u32 *bcnt = (u32 *)(zb + p.z_bcnt), *nnanrow = (u32 *)(zb + p.z_nnan), *ovf = (u32 *)(zb + p.z_ovf);
+    u32 *bflag = (u32 *)(zb + p.z_bflag), *nanf = (u32 *)(zb + p.z_nanf);
+
+    const char *env = getenv("SD_BIG_IMPL");                 // 1: chunked route for every row (A/B timing, cross-check)
+    const bool buckets = !(env && atoi(env) == 1);
+    const int NB = p.NB;
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) {
         int v = 0;
         if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
     }
-    auto ksort = chunk_sort_kernel;
-    SD_HIP(hipFuncSetAttribute((const void *)ksort, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BigCfg::LDS_BYTES));
-    auto ks2 = chunk_search_kernel<2>;
-    auto ks3 = chunk_search_kernel<3>;
-    SD_HIP(hipFuncSetAttribute((const void *)ks2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BigCfg::LDS_BYTES));
-    SD_HIP(hipFuncSetAttribute((const void *)ks3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BigCfg::LDS_BYTES));
-    for (i64 row0 = 0; row0 < T; row0 += rpb) {
-        i64 rows = T - row0 < rpb ? T - row0 : rpb;
-        SD_HIP(hipMemsetAsync(nanrow, 0, (size_t)rows * 4, s));
-        hipLaunchKernelGGL(ksort, dim3((unsigned)nch, (unsigned)rows), dim3(BIG_NT), BigCfg::LDS_BYTES, s, Y, n, row0,
-                           sorted, sstride, nanrow);
-        // persistent search grid: a multiple of the number of target chunks, about one workgroup per CU.
-        // An explicit target list may point anywhere, so every chunk is searched; a contiguous block
-        // (targets == NULL) restricts the search to the chunks it overlaps.
-        i64 qc0 = targets ? 0 : tbegin / BIG_C;
-        i64 qc1 = targets ? nch : (tbegin + m + BIG_C - 1) / BIG_C;
-        i64 nqc = qc1 - qc0;
-        i64 rgroups = cus / nqc;
+    auto k_cs = chunk_sort_kernel;
+    auto k_cq = chunk_search_kernel;
+    auto k_sp = bucket_splitters_kernel;
+    auto k_bp = bucket_packed_kernel;
+    auto k_bs = bucket_search_kernel;
+    const size_t lds_bk = BkCfg::LDS_BYTES + (size_t)BK_NT * 8;
+    SD_HIP(hipFuncSetAttribute((const void *)k_cs, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BigCfg::LDS_BYTES));
+    SD_HIP(hipFuncSetAttribute((const void *)k_cq, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BigCfg::LDS_BYTES));
+    SD_HIP(hipFuncSetAttribute((const void *)k_sp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SsCfg::LDS_BYTES));
+    SD_HIP(hipFuncSetAttribute((const void *)k_bp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bk));
+    SD_HIP(hipFuncSetAttribute((const void *)k_bs, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BkCfg::LDS_BYTES));
+
+    for (i64 row0 = 0; row0 < T; row0 += p.rpb) {
+        const i64 rows = T - row0 < p.rpb ? T - row0 : p.rpb;
+        SD_HIP(hipMemsetAsync(zb, 0, p.zero_bytes, s));
+        const u32 *fallback_rows = nullptr;                  // chunked route: every row
+        const u32 *nn_for_fold = nanf;
+        if (buckets) {
+            hipLaunchKernelGGL(k_sp, dim3((unsigned)rows), dim3(256), SsCfg::LDS_BYTES, s, Y, n, row0, NB, spl);
+            hipLaunchKernelGGL(bucket_partition_kernel, dim3((unsigned)((n + 16383) / 16384), (unsigned)rows), dim3(1024), 0,
+                               s, Y, n, row0, NB, (const double *)spl, bcnt, nnanrow, ovf, bval, bidx, ab);
+            hipLaunchKernelGGL(k_bp, dim3((unsigned)NB, (unsigned)rows), dim3(BK_NT), lds_bk, s, n, NB, (const u32 *)bcnt,
+                               (const u32 *)nnanrow, (const u32 *)ovf, (const double *)bval, (const u32 *)bidx, bflag, ab);
+            hipLaunchKernelGGL(k_bs, dim3((unsigned)NB, (unsigned)rows), dim3(BK_NT), BkCfg::LDS_BYTES, s, n, NB,
+                               (const u32 *)bcnt, (const u32 *)nnanrow, (const u32 *)bflag, (const double *)bval,
+                               (const u32 *)bidx, ab);
+            fallback_rows = ovf;                             // chunked route: only rows whose partition overflowed
+            nn_for_fold = nnanrow;
+        }
+        hipLaunchKernelGGL(k_cs, dim3((unsigned)p.nch, (unsigned)rows), dim3(BIG_NT), BigCfg::LDS_BYTES, s, Y, n, row0,
+                           sorted, p.sstride, nanf, fallback_rows);
+        i64 rgroups = cus / p.nch;
         if (rgroups < 1) rgroups = 1;
         if (rgroups > rows) rgroups = rows;
-        unsigned G = (unsigned)(rgroups * nqc);
-        if (J == 2)
-            hipLaunchKernelGGL(ks2, dim3(G), dim3(BIG_NT), BigCfg::LDS_BYTES, s, Y, n, row0, rows, sorted, sstride,
-                               nanrow, (int)nch, (int)qc0, (int)nqc, totals);
-        else
-            hipLaunchKernelGGL(ks3, dim3(G), dim3(BIG_NT), BigCfg::LDS_BYTES, s, Y, n, row0, rows, sorted, sstride,
-                               nanrow, (int)nch, (int)qc0, (int)nqc, totals);
+        hipLaunchKernelGGL(k_cq, dim3((unsigned)(rgroups * p.nch)), dim3(BIG_NT), BigCfg::LDS_BYTES, s, Y, n, row0, rows,
+                           (const double *)sorted, p.sstride, (const u32 *)nanf, (int)p.nch, fallback_rows, ab);
+        SD_HIP(hipGetLastError());
+        const int first = row0 == 0;
+        dim3 grid((unsigned)((m + 63) / 64));
+        SD_DISPATCH_J(J, hipLaunchKernelGGL((rank_accumulate2_kernel<J_>), grid, dim3(1024), 0, s, (const AB2 *)ab,
+                                            nn_for_fold, rows, n, targets, tbegin, m, out, first));
         SD_HIP(hipGetLastError());
     }
-    hipLaunchKernelGGL(big_gather_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s, totals, n, J - 1, targets,
-                       tbegin, m, out);
-    SD_HIP(hipGetLastError());
     return SD_OK;
 }
 

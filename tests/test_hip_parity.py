@@ -388,3 +388,23 @@ def test_row_batching(eng, oracle, monkeypatch):
     monkeypatch.setenv("SD_RANK_ROWS_PER_BATCH", "2")
     Xb = rng.normal(size=(5, 17000))
     assert (eng.mbd_counts(Xb, None, 2, algo="rank") == oracle.mbd_counts(Xb, None, 2)).all()
+
+
+def test_big_n_routes(eng, oracle, monkeypatch):
+    """n > 16384: value-bucket route (default), its overflow fallback (a row where most values tie cannot be cut
+    into buckets of 8192) and the chunked route forced for every row: identical integers."""
+    rng = np.random.default_rng(2024)
+    T, n = 4, 30000
+    X = rng.normal(size=(T, n)).cumsum(axis=0)
+    X[1, rng.random(n) < 0.7] = 0.25            # 70 % of row 1 tied on one value: bucket overflow -> chunked fallback
+    X[2] = np.round(X[2], 1)                    # tie-heavy row: buckets flagged for the search kernel
+    X[3, ::7] = np.nan
+    X[3, 5] = np.inf
+    X[3, 6] = -np.inf
+    want = oracle.mbd_counts(X, None, 2)
+    assert (eng.mbd_counts(X, None, 2, algo="rank") == want).all()
+    monkeypatch.setenv("SD_BIG_IMPL", "1")
+    assert (eng.mbd_counts(X, None, 2, algo="rank") == want).all()
+    monkeypatch.delenv("SD_BIG_IMPL")
+    tg = np.array([0, 29999, 12345, 7])
+    assert (eng.mbd_counts(X, tg, 3, algo="rank") == oracle.mbd_counts(X, tg, 3)).all()
