@@ -88,11 +88,11 @@ def main():
     emit(kernel="K5 l1_depth", workload="n=1e5 points in R^3", seconds=t, unit="point-pairs/s", value=1e10 / t,
          cpu_value=2000 * 1e5 / ct, cpu_cores=cores, cpu_sample="2000 targets")
 
-    # chunked K1+K2: config 3 on one GPU
+    # large-n K1+K2 (value buckets): config 3 on one GPU
     n, T = 100000, 256
     Xd = torch.randn(T, n, dtype=torch.float64, device="cuda").cumsum(0)
     t = tm(lambda: engine.mbd_counts(Xd, None, 2, algo="rank", return_tensor=True), 3)
-    emit(kernel="K1+K2 chunked rank (chunk_sort + chunk_search)", workload=f"{n} curves x {T} timepoints (config 3), 1 GPU",
+    emit(kernel="K1+K2 large-n rank (value buckets)", workload=f"{n} curves x {T} timepoints (config 3), 1 GPU",
          seconds=t, unit="curve-pairs/s", value=n * (n - 1) / t,
          algorithmic_bytes=8.0 * T * 2 * n + 8.0 * n, roofline_frac=(8.0 * T * 2 * n + 8.0 * n) / t / 8e12)
     # external targets (homogeneity P3 shape)
