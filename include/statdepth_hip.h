@@ -106,6 +106,15 @@ int sd_mbd_counts_range(const double *X, int64_t T, int64_t n, int64_t st, int64
 int sd_mbd_external_counts(const double *X, int64_t T, int64_t n, const double *Q, int64_t m, int J,
                            int64_t *out, void *ws, size_t ws_bytes, void *stream);
 
+/* Band totals of one target inside an explicit subset of the curves, for nb (subset, target) pairs in one launch:
+ * the K-block sampled estimator (_samplefunctionaldepth, _functional.py:170-182) evaluates
+ * _univariate_band_depth on n*K small blocks.  X time-major dense (st = n, sn = 1).
+ * members: int32[nb*bs] column indices, -1 = padding; target: int32[nb], each a member of its block.
+ * out[k*(J-1)+(j-2)] = sum_t #{j-subsets of the block's OTHER members whose band contains the target at t}.
+ * Host: depth = sum_j out/T / C(block size, j). */
+int sd_mbd_subset_counts(const double *X, int64_t T, int64_t n, const int32_t *members, int64_t nb, int bs,
+                         const int32_t *target, int J, int64_t *out, void *stream);
+
 /* Finest-granularity form of K1 (tests, diagnostics): AB[(q*T + t)*2 + {0,1}] =
  * (#curves strictly above, #strictly below) target q at t, as uint32. */
 int sd_above_below(const double *X, int64_t T, int64_t n, int64_t st, int64_t sn,

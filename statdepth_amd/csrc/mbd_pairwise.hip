@@ -161,4 +161,58 @@ int launch_above_below(const double *Y, i64 T, i64 n, const i64 *targets, i64 m,
     return SD_OK;
 }
 
+// ---------------------------------------------------------------------------
+// Band totals of one target inside an explicit SUBSET of the curves, for many (subset, target) pairs at once:
+// the K-block sampled estimator (_samplefunctionaldepth, _functional.py:170-182) calls
+// _univariate_band_depth once per (target, block); here every block is one workgroup of one launch.
+// Lanes = members of the block (gathered columns), waves = timepoints; A/B/NaN counts by ballot + popcount.
+// members[k*bs + c] = column index or -1 (padding); the target column must be among the members.
+// ---------------------------------------------------------------------------
+template <int J>
+__global__ __launch_bounds__(256) void mbd_subset_kernel(const double *__restrict__ Y, i64 T, i64 n,
+                                                         const int *__restrict__ members, int bs,
+                                                         const int *__restrict__ target, u64 *__restrict__ out) {
+    __shared__ u64 red[4][JMAX - 1];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const i64 k = blockIdx.x;
+    const int *mem = members + k * bs;
+    const int tg = target[k];
+    u32 nmem = 0;                                    // members other than the target
+    for (int c = lane; c < bs; c += 64) nmem += (mem[c] >= 0 && mem[c] != tg);
+    for (int o = 32; o > 0; o >>= 1) nmem += __shfl_xor(nmem, o);
+    u64 acc[JMAX - 1];
+#pragma unroll
+    for (int j = 0; j < JMAX - 1; ++j) acc[j] = 0;
+    for (i64 t = wave; t < T; t += 4) {
+        const double *row = Y + t * n;
+        const double x = row[tg];
+        u32 A = 0, B = 0, N = 0;
+        for (int c0 = 0; c0 < bs; c0 += 64) {
+            const int c = c0 + lane;
+            const int col = (c < bs) ? mem[c] : -1;
+            const bool live = col >= 0 && col != tg;
+            const double v = live ? row[col] : x;
+            A += (u32)__popcll(__ballot(live && v > x));
+            B += (u32)__popcll(__ballot(live && v < x));
+            N += (u32)__popcll(__ballot(live && v != v));
+        }
+        if (x == x) band_counts_add<J>(A, B, N, (u64)nmem, acc);
+    }
+    if (lane == 0)
+#pragma unroll
+        for (int j = 0; j < J - 1; ++j) red[wave][j] = acc[j];
+    __syncthreads();
+    if (threadIdx.x == 0)
+#pragma unroll
+        for (int j = 0; j < J - 1; ++j) out[k * (J - 1) + j] = red[0][j] + red[1][j] + red[2][j] + red[3][j];
+}
+
+int launch_mbd_subsets(const double *Y, i64 T, i64 n, const int *members, i64 nb, int bs, const int *target, int J,
+                       u64 *out, hipStream_t s) {
+    SD_DISPATCH_J(J, hipLaunchKernelGGL((mbd_subset_kernel<J_>), dim3((unsigned)nb), dim3(256), 0, s, Y, T, n, members,
+                                        bs, target, out));
+    SD_HIP(hipGetLastError());
+    return SD_OK;
+}
+
 }  // namespace sd

@@ -220,6 +220,16 @@ int sd_mbd_external_counts(const double *X, int64_t T, int64_t n, const double *
     return launch_mbd_external(X, T, n, Q, m, J, nan_cnt, (u64 *)out, s);
 }
 
+int sd_mbd_subset_counts(const double *X, int64_t T, int64_t n, const int32_t *members, int64_t nb, int bs,
+                         const int32_t *target, int J, int64_t *out, void *stream) {
+    if (!X || !members || !target || !out) return fail(SD_ERR_INVALID, "null pointer");
+    if (T <= 0 || n <= 0 || nb < 0 || bs <= 0) return fail(SD_ERR_INVALID, "bad shape");
+    int rc = check_count_range(T, bs, J);
+    if (rc) return rc;
+    if (nb == 0) return SD_OK;
+    return launch_mbd_subsets(X, T, n, members, nb, bs, target, J, (u64 *)out, (hipStream_t)stream);
+}
+
 int sd_above_below(const double *X, int64_t T, int64_t n, int64_t st, int64_t sn,
                    const int64_t *targets, int64_t m, uint32_t *AB,
                    void *ws, size_t ws_bytes, void *stream) {

@@ -53,6 +53,8 @@ int launch_mbd_pairwise(const double *Y, i64 T, i64 n, const i64 *targets, i64 t
 // external targets Q (T x m, time-major) against the n curves of Y
 int launch_mbd_external(const double *Y, i64 T, i64 n, const double *Q, i64 m, int J, const u32 *nan_cnt, u64 *out,
                         hipStream_t s);
+int launch_mbd_subsets(const double *Y, i64 T, i64 n, const int *members, i64 nb, int bs, const int *target, int J,
+                       u64 *out, hipStream_t s);
 int launch_above_below(const double *Y, i64 T, i64 n, const i64 *targets, i64 m, u32 *AB, hipStream_t s);
 // K1+K2 rank formulation
 size_t mbd_rank_workspace_bytes(i64 T, i64 n, int J);

@@ -134,17 +134,43 @@ def _samplefunctionaldepth(data: List[pd.DataFrame], K: int, to_compute: Union[l
     if cdef == 'r2_enum':
         raise NotImplementedError
 
+    batched = (cdef == 'r2' and relax)
+    blocks, block_targets = [], []           # column positions (in data[0]) of every block, in draw order
+    full = data[0]
     for col in orig.columns:
         depths = []
         for _ in range(K):
             t = df.sample(n=ss, axis=1)                  # (:176) global numpy RNG
             df = df.drop(t.columns, axis=1)              # (:177) without replacement across blocks
+            members = list(t.columns)
+            if col not in members:
+                members.append(col)                      # (:178) force the target into the block
+            if batched:
+                blocks.append(full.columns.get_indexer(members))
+                block_targets.append(full.columns.get_loc(col))
+                continue
             t = t.copy()
-            t.loc[:, col] = orig.loc[:, col]             # (:178) force the target into the block
+            t.loc[:, col] = orig.loc[:, col]
             if cdef == 'r2':
                 depths.append(_univariate_depths(t, [col], J, relax, device=device, algo='pairwise')[0])
             else:
                 depths.append(_callable_band_depth(t, col, relax, cdef, J))
-        samples.append(np.mean(depths))                  # (:182)
+        if not batched:
+            samples.append(np.mean(depths))              # (:182)
         df = orig.copy()                                 # (:183) -- the pool shrinks to `cols`, as in the reference
+    if batched:
+        # every (target, block) pair of the estimator in ONE launch
+        width = max(len(b) for b in blocks)
+        mem = np.full((len(blocks), width), -1, dtype=np.int32)
+        for i, b in enumerate(blocks):
+            mem[i, :len(b)] = b
+        X = full.to_numpy(dtype=np.float64)
+        T = X.shape[0]
+        counts = engine.mbd_subset_counts(X, mem, np.asarray(block_targets, dtype=np.int32), J=J,
+                                          device=device).astype(np.float64) / T
+        sizes = np.array([len(b) for b in blocks], dtype=np.float64)
+        depth = np.zeros(len(blocks))
+        for j in range(2, J + 1):
+            depth += counts[:, j - 2] / binom(sizes, j)  # (:253) n = block size including the target
+        samples = [np.mean(depth[i * K:(i + 1) * K]) for i in range(len(orig.columns))]
     return pd.Series(index=df.columns, data=samples)     # (:186)

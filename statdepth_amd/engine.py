@@ -148,6 +148,29 @@ def mbd_external_counts(X, Q, J=2, device=None):
     return out.cpu().numpy()
 
 
+def mbd_subset_counts(X, members, targets, J=2, device=None):
+    """int64[nb, J-1]: band totals of targets[k] inside the curves members[k] (-1 padded) -- sd_mbd_subset_counts."""
+    t = torch()
+    lib = _native.require_device()
+    dev = _device(device)
+    Xd = X if (isinstance(X, t.Tensor) and X.is_cuda) else t.from_numpy(
+        np.ascontiguousarray(np.asarray(X, dtype=np.float64))).to(dev)
+    Xd = Xd.contiguous()
+    T, n = Xd.shape
+    mem = np.ascontiguousarray(np.asarray(members, dtype=np.int32))
+    tg = np.ascontiguousarray(np.asarray(targets, dtype=np.int32))
+    nb, bs = mem.shape
+    if len(tg) != nb:
+        raise ValueError("one target per block")
+    out = t.empty((nb, J - 1), dtype=t.int64, device=dev)
+    if nb == 0:
+        return out.cpu().numpy()
+    md, td = t.from_numpy(mem).to(dev), t.from_numpy(tg).to(dev)
+    check(lib.sd_mbd_subset_counts(Xd.data_ptr(), T, n, md.data_ptr(), nb, bs, td.data_ptr(), J, out.data_ptr(),
+                                   _stream_ptr(dev)))
+    return out.cpu().numpy()
+
+
 def above_below(X, targets=None, device=None):
     """uint32 -> int64 [m, T, 2] strictly-above / strictly-below counts (sd_above_below)."""
     t = torch()

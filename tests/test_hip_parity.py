@@ -103,6 +103,29 @@ def test_golden_homogeneity(name):
     assert F.equals(Fc) and G.equals(Gc)           # inputs are not mutated (the reference does mutate F)
 
 
+def test_subset_counts_vs_oracle(eng, oracle):
+    """sd_mbd_subset_counts: depth of a target inside an explicit block of curves == oracle on the sub-matrix."""
+    rng = np.random.default_rng(41)
+    X = np.round(rng.normal(size=(23, 90)).cumsum(axis=0), 1)
+    X[4, 17] = np.nan
+    blocks, tgs = [], []
+    for k in range(40):
+        size = int(rng.integers(3, 70))
+        mem = rng.choice(90, size=size, replace=False)
+        blocks.append(mem)
+        tgs.append(int(mem[rng.integers(0, size)]))
+    width = max(len(b) for b in blocks)
+    M = np.full((len(blocks), width), -1, dtype=np.int32)
+    for i, b in enumerate(blocks):
+        M[i, :len(b)] = b
+    for J in (2, 3):
+        got = eng.mbd_subset_counts(X, M, np.array(tgs), J=J)
+        for i, (b, tg) in enumerate(zip(blocks, tgs)):
+            sub = X[:, b]
+            want = oracle.mbd_counts(sub, [list(b).index(tg)], J)[0]
+            assert (got[i] == want).all()
+
+
 def test_external_counts_vs_oracle(eng, oracle):
     """sd_mbd_external_counts == oracle depth counts of g inside F u {g}, for every g at once."""
     rng = np.random.default_rng(12)
