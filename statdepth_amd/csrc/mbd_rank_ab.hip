@@ -389,6 +389,15 @@ static i64 ab_rows_per_batch(i64 T, i64 n) {
     return r < T ? r : T;
 }
 
+// mbd_rank_bucket.hip
+bool mbd_rank_bucket_supported(i64 T, i64 n, int J);
+size_t mbd_rank_bucket_workspace_bytes(i64 rows, i64 n, int J);
+int launch_rank_bucket(const double *Y, i64 n, i64 row0, i64 rows, int J, u64 *partial, u32 *nnan,
+                       unsigned char *rowflag, int *G_out, hipStream_t s);
+int launch_rank_finalize(const u64 *partial, int G, const u32 *AB, const u32 *nnan, const unsigned char *rowflag,
+                         i64 rows, i64 n, const i64 *targets, i64 tbegin, i64 m, int J, u64 *out, int first,
+                         hipStream_t s);
+
 bool mbd_rank_supported(i64 T, i64 n, int J) {
     (void)T;
     return n >= 2 && n <= 16384 && J >= 2 && J <= JMAX;
@@ -398,6 +407,7 @@ size_t mbd_rank_workspace_bytes(i64 T, i64 n, int J) {
     if (!mbd_rank_supported(T, n, J)) return 0;
     i64 rpb = ab_rows_per_batch(T, n);
     size_t need = align_up((size_t)rpb * n * 4, 256) + 2 * align_up((size_t)rpb * 4, 256) + 512;
+    if (mbd_rank_bucket_supported(T, n, J)) need += mbd_rank_bucket_workspace_bytes(rpb, n, J);
     size_t v1 = (size_t)(T < 1024 ? T : 1024) * (J <= 3 ? J - 1 : 0) * n * 8;   // first-generation kernel's partial sums
     return need > v1 ? need : v1;
 }
@@ -413,6 +423,11 @@ static int launch_sorts(const double *Y, i64 n, i64 row0, i64 rows, u32 *AB, u32
     SD_HIP(hipFuncSetAttribute((const void *)ks, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES));
     if (impl == 2) {   // full keys + search for every row (A/B timing, cross-check)
         hipLaunchKernelGGL(ks, dim3(G), dim3(NT), C::LDS_BYTES, s, Y, n, row0, rows, AB, nnan, 0);
+        SD_HIP(hipGetLastError());
+        return SD_OK;
+    }
+    if (impl == 4) {   // the bucket kernel ranked the rows; only those it deferred are sorted here
+        hipLaunchKernelGGL(ks, dim3(G), dim3(NT), C::LDS_BYTES, s, Y, n, row0, rows, AB, nnan, 1);
         SD_HIP(hipGetLastError());
         return SD_OK;
     }
@@ -435,18 +450,30 @@ int launch_mbd_rank_v1(const double *Y, i64 T, i64 n, const i64 *targets, i64 tb
 int launch_mbd_rank(const double *Y, i64 T, i64 n, const i64 *targets, i64 tbegin, i64 m, int J,
                     u64 *out, void *ws, size_t ws_bytes, hipStream_t s) {
     if (!mbd_rank_supported(T, n, J)) return fail(SD_ERR_UNSUPPORTED, "rank kernels cover 2 <= n <= 16384");
-    // SD_RANK_IMPL (A/B timing, cross-checks): 2 = search kernel for every row, 1 = first-generation kernel
+    // SD_RANK_IMPL (A/B timing, cross-checks): 4 = bucket kernel (default where it applies), 3 = packed-key sort,
+    // 2 = search kernel for every row, 1 = first-generation kernel
     const char *env = getenv("SD_RANK_IMPL");
-    const int impl = env ? atoi(env) : 3;
+    int impl = env ? atoi(env) : 4;
+    if (impl == 4 && !mbd_rank_bucket_supported(T, n, J)) impl = 3;
     if (impl == 1 && J <= 3) return launch_mbd_rank_v1(Y, T, n, targets, tbegin, m, J, out, ws, ws_bytes, s);
     const i64 rpb = ab_rows_per_batch(T, n);
     Carver cv(ws, ws_bytes);
     u32 *AB = (u32 *)cv.take((size_t)rpb * n * 4);
     u32 *nnan = (u32 *)cv.take((size_t)rpb * 4);
     if (!AB || !nnan) return fail(SD_ERR_WORKSPACE, "rank workspace too small");
+    u64 *partial = nullptr;
+    unsigned char *rowflag = nullptr;
+    if (impl == 4) {
+        const size_t pb = mbd_rank_bucket_workspace_bytes(rpb, n, J) - align_up((size_t)rpb, 256) - 512;
+        partial = (u64 *)cv.take(pb);
+        rowflag = (unsigned char *)cv.take((size_t)rpb);
+        if (!partial || !rowflag) return fail(SD_ERR_WORKSPACE, "rank workspace too small (bucket kernel)");
+    }
     for (i64 row0 = 0; row0 < T; row0 += rpb) {
         const i64 rows = T - row0 < rpb ? T - row0 : rpb;
         int rc;
+        int G = 0;
+        if (impl == 4 && (rc = launch_rank_bucket(Y, n, row0, rows, J, partial, nnan, rowflag, &G, s))) return rc;
         // E = 16 keys per thread throughout; smaller rows take smaller workgroups so that several rows are in
         // flight per CU (n = 4000: 4 workgroups of 256 threads per CU, 0.053 ms against 0.091 ms for 1024 x 4)
         if (n <= 1024) rc = launch_sorts<64, 16>(Y, n, row0, rows, AB, nnan, impl, s);
@@ -457,6 +484,11 @@ int launch_mbd_rank(const double *Y, i64 T, i64 n, const i64 *targets, i64 tbegi
         if (rc) return rc;
         dim3 grid((unsigned)((m + 63) / 64));
         const int first = row0 == 0;
+        if (impl == 4) {
+            if ((rc = launch_rank_finalize(partial, G, AB, nnan, rowflag, rows, n, targets, tbegin, m, J, out, first, s)))
+                return rc;
+            continue;
+        }
         if (!targets && (n % 4) == 0 && (tbegin % 4) == 0 && (m % 4) == 0 && J <= 3) {
             SD_DISPATCH_J(J, hipLaunchKernelGGL((rank_accumulate4_kernel<J_>), grid, dim3(1024), 0, s, (const u32 *)AB,
                                                 (const u32 *)nnan, rows, n, tbegin, m, out, first));
