@@ -12,11 +12,12 @@
 //      LDS atomic per key on a packed u16 histogram, whose return value is the key's slot inside its bucket;
 //      (2) exclusive prefix sum of the NB counters; (3) keys scattered into bucket order; (4) every key
 //      compares itself with the members of its own bucket: B = base + #(y < x), A = n - base - #(y <= x).
-//      Keys past the end of a bucket belong to later buckets and compare greater, so the member loop needs
-//      no bounds.  Ties are exact by construction (equal values share a bucket).  The per-curve band counts
+//      Keys past the end of a bucket belong to later buckets and compare greater (NaN sentinels follow the
+//      last one), so the member loop needs no bounds.  Ties are exact by construction (equal values share a bucket).  The per-curve band counts
 //      are accumulated in REGISTERS across the workgroup's rows; one partial total per (workgroup, curve)
 //      goes to HBM at the end: the matrix is read once and nothing per (row, curve) is ever written.
-//      A row with a NaN or an infinity, a degenerate range or a bucket of more than CAP keys (heavy ties,
+//      NaNs stay out of the histogram and weigh in as pandas' skipna does; +-inf take the end buckets.
+//      A row whose finite values are all equal or that has a bucket of more than CAP keys (heavy ties,
 //      clustered data) is left to the sort + search kernel (rank_search_kernel, mbd_rank_ab.hip), which
 //      writes that row of the pair image.
 //   Z  rank_finalize_kernel -- totals of the requested targets = sum of the workgroups' partials + the fold
@@ -31,14 +32,43 @@ namespace sd {
 
 constexpr u32 RB_AB_SPECIAL = 0xFFFFFFFFu;     // same encodings as mbd_rank_ab.hip
 constexpr u32 RB_ROW_DEFERRED = 0xFFFFFFFFu;
-constexpr int RB_PAD = 8;                      // +inf sentinels behind the bucket-ordered keys
+constexpr int RB_PAD = 8;                      // NaN sentinels behind the bucket-ordered keys (never < or <= anything)
+constexpr u32 RB_NOKEY = 0xFFFFFFFFu;          // bs[e] / bc[e]: no curve here, or a NaN
 
-__device__ __forceinline__ u32 rb_wave_incl_scan(u32 v, int lane) {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        u32 o = __shfl_up(v, d, 64);
-        if (lane >= d) v += o;
-    }
+// ---- wave64 cross-lane helpers on DPP (no LDS traffic, no ds_bpermute latency chain) ----
+// row_shr:1,2,4,8 scan inside each row of 16 lanes, then row_bcast:15 / row_bcast:31 carry the row totals up.
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ u32 rb_dpp(u32 old, u32 v) {
+    return (u32)__builtin_amdgcn_update_dpp((int)old, (int)v, CTRL, ROWMASK, 0xF, false);
+}
+
+__device__ __forceinline__ u32 rb_wave_incl_scan(u32 v) {
+    v += rb_dpp<0x111, 0xF>(0u, v);
+    v += rb_dpp<0x112, 0xF>(0u, v);
+    v += rb_dpp<0x114, 0xF>(0u, v);
+    v += rb_dpp<0x118, 0xF>(0u, v);
+    v += rb_dpp<0x142, 0xA>(0u, v);
+    v += rb_dpp<0x143, 0xC>(0u, v);
+    return v;
+}
+
+template <int CTRL, int ROWMASK, bool MAX>
+__device__ __forceinline__ double rb_mm_step(double v) {
+    const u64 b = (u64)__double_as_longlong(v);
+    const u32 l = rb_dpp<CTRL, ROWMASK>((u32)b, (u32)b), h = rb_dpp<CTRL, ROWMASK>((u32)(b >> 32), (u32)(b >> 32));
+    const double o = __longlong_as_double((long long)(((u64)h << 32) | l));
+    return MAX ? (o > v ? o : v) : (o < v ? o : v);
+}
+
+// min (or max) over the wave, valid in lane 63
+template <bool MAX>
+__device__ __forceinline__ double rb_wave_minmax_last(double v) {
+    v = rb_mm_step<0x111, 0xF, MAX>(v);
+    v = rb_mm_step<0x112, 0xF, MAX>(v);
+    v = rb_mm_step<0x114, 0xF, MAX>(v);
+    v = rb_mm_step<0x118, 0xF, MAX>(v);
+    v = rb_mm_step<0x142, 0xA, MAX>(v);
+    v = rb_mm_step<0x143, 0xC, MAX>(v);
     return v;
 }
 
@@ -54,14 +84,17 @@ struct RBCfg {
     }
 };
 
-template <int NT, int E, int LNB, int J, int CAP, int U>
+// DBG (timing experiments only, results invalid): 1 = stop after the range, 2 = after the histogram, 3 = after the
+// prefix sum, 4 = after the scatter
+template <int NT, int E, int LNB, int J, int CAP, int U, int DBG = 0>
 __global__ __launch_bounds__(NT) void rank_bucket_kernel(const double *__restrict__ Y, i64 n64, i64 row0, i64 rows,
                                                          u64 *__restrict__ partial, u32 *__restrict__ nnan_out,
                                                          unsigned char *__restrict__ rowflag) {
     using C = RBCfg<NT, E, LNB>;
     constexpr int NB = C::NB, NW = C::NW, W = C::W;
     static_assert(U >= 1 && U - 1 <= RB_PAD, "member loop reads at most RB_PAD keys past the end");
-    static_assert(CAP < 256 && NB <= 32768, "packing of (base, count, slot)");
+    static_assert(CAP < 255 && NB <= 32768, "packing of (base, count, slot)");
+    constexpr int NACC = (J == 2) ? 1 : (J - 1);
     extern __shared__ double Sm[];
     const int n = (int)n64;
     double *S = Sm;                                                   // keys in bucket order + sentinels
@@ -74,7 +107,7 @@ __global__ __launch_bounds__(NT) void rank_bucket_kernel(const double *__restric
     int t = t0;
 
     // one-time LDS setup: sentinels, empty histogram
-    if (t < RB_PAD) S[n + t] = INF;
+    if (t < RB_PAD) S[n + t] = __builtin_nan("");
 #pragma unroll
     for (int w = 0; w < W; ++w) H[t * W + w] = 0;
     if (t < 2) H[NB / 2 + t] = 0;
@@ -85,13 +118,14 @@ __global__ __launch_bounds__(NT) void rank_bucket_kernel(const double *__restric
     auto load_row = [&](i64 r, double (&dst)[E]) {
         const double *rp = Y + (row0 + r) * n + t;
 #pragma unroll
-        for (int e = 0; e < E; ++e) dst[e] = valid(e) ? rp[e * NT] : 0.0;
+        for (int e = 0; e < E; ++e) dst[e] = valid(e) ? rp[e * NT] : __builtin_nan("");
     };
-    u64 acc[E][JMAX - 1];
+    // J == 2: acc[e][0] = 2 * (sum of band counts) (one accumulator, see the fold below); else acc[e][j-2]
+    u64 acc[E][NACC];
 #pragma unroll
     for (int e = 0; e < E; ++e)
 #pragma unroll
-        for (int j = 0; j < JMAX - 1; ++j) acc[e][j] = 0;
+        for (int j = 0; j < NACC; ++j) acc[e][j] = 0;
 
     if ((i64)blockIdx.x < rows) load_row(blockIdx.x, k);
     int par = 0;
@@ -103,28 +137,21 @@ __global__ __launch_bounds__(NT) void rank_bucket_kernel(const double *__restric
         t = t0;
         asm volatile("" : "+v"(t));
         const int lane = t & 63, wave = t >> 6;
-        // ---- (0) range of the row; non-finite values send the row to the search kernel ----
+        // ---- (0) range of the finite values of the row (NaN: pandas skipna, _containment.py:68-69) ----
         double mn = INF, mx = -INF;
-        int bad = 0;
 #pragma unroll
         for (int e = 0; e < E; ++e) {
-            if (valid(e)) {
-                const double x = k[e];
-                bad |= !(__builtin_fabs(x) < INF);                    // NaN or +-inf
-                mn = x < mn ? x : mn;
-                mx = x > mx ? x : mx;
-            }
+            const double x = k[e];                                    // slots beyond n hold NaN
+            const bool fin = __builtin_fabs(x) < INF;
+            mn = (fin && x < mn) ? x : mn;
+            mx = (fin && x > mx) ? x : mx;
         }
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) {
-            const double a = __shfl_xor(mn, d, 64), b = __shfl_xor(mx, d, 64);
-            mn = a < mn ? a : mn;
-            mx = b > mx ? b : mx;
-        }
+        mn = rb_wave_minmax_last<false>(mn);
+        mx = rb_wave_minmax_last<true>(mx);
         double *redp = red + par * 2 * NW;
-        if (lane == 0) { redp[2 * wave] = mn; redp[2 * wave + 1] = mx; }
+        if (lane == 63) { redp[2 * wave] = mn; redp[2 * wave + 1] = mx; }
         par ^= 1;
-        const int anybad = __syncthreads_or(bad);                     // barrier 1 (histogram is zero, S is free)
+        __syncthreads();                                              // barrier 1 (histogram is zero, S is free)
         double lo = INF, hi = -INF;
 #pragma unroll
         for (int w = 0; w < NW; ++w) {
@@ -135,73 +162,113 @@ __global__ __launch_bounds__(NT) void rank_bucket_kernel(const double *__restric
         const double scale = (double)NB / (hi - lo);                  // range overflow -> 0 -> one crowded bucket
         // Every decision below is block-uniform.  The next row is loaded at ONE place (two load sites would
         // keep two copies of the key registers alive across the loop).
-        bool go = !(anybad || !(hi > lo) || !(scale < INF));
+        bool go = (hi > lo) && (scale < INF);                         // else: all finite values equal, or none
+        if constexpr (DBG == 1) go = false;
         u32 bs[E];
+        u32 nn = 0;                                                   // NaN others of this row (block-uniform)
         if (go) {
-            // ---- (1) bucket + slot ----
+            // ---- (1) bucket + slot.  clamp(fl(fl(x - lo) * scale)) is non-decreasing in x; -inf and +inf
+            //      land in the first and last bucket ----
 #pragma unroll
             for (int e = 0; e < E; ++e) {
-                bs[e] = 0;
-                if (valid(e)) {
-                    const double u = (k[e] - lo) * scale;             // finite, >= 0, monotone in k[e]
-                    const u32 b = (u32)(u < (double)(NB - 1) ? u : (double)(NB - 1));
+                bs[e] = RB_NOKEY;
+                const double x = k[e];
+                if (x == x) {
+                    double u = (x - lo) * scale;
+                    u = u > 0.0 ? u : 0.0;
+                    u = u < (double)(NB - 1) ? u : (double)(NB - 1);
+                    const u32 b = (u32)u;
                     const u32 sh = (b & 1u) * 16u;
                     const u32 old = atomicAdd(&H[b >> 1], 1u << sh);
                     bs[e] = b | (((old >> sh) & 0xFFFFu) << 16);
                 }
             }
             __syncthreads();                                          // barrier 2
-            // ---- (2) exclusive prefix sum over the counters; crowded bucket -> defer ----
-            u32 ex[2 * W], run = 0;
-            int over = 0;
+            if constexpr (DBG == 2) {
 #pragma unroll
-            for (int w = 0; w < W; ++w) {
-                const u32 x = H[t * W + w];
-                const u32 c0 = x & 0xFFFFu, c1 = x >> 16;
-                over |= (c0 > (u32)CAP) | (c1 > (u32)CAP);
-                ex[2 * w] = run;
-                run += c0;
-                ex[2 * w + 1] = run;
-                run += c1;
+                for (int w = 0; w < W; ++w) H[t * W + w] = 0;
+                go = false;
             }
-            const u32 incl = rb_wave_incl_scan(run, lane);
-            if (lane == 63) wtot[wave] = incl;
-            go = !__syncthreads_or(over);                             // barrier 3
-            u32 base0 = incl - run;
+            if constexpr (DBG != 2) {
+                // ---- (2) exclusive prefix sum over the counters; a crowded bucket defers the row ----
+                u32 hw[W], sum = 0, ov = 0;
 #pragma unroll
-            for (int w = 0; w < NW; ++w) base0 += (w < wave) ? wtot[w] : 0u;
-            // a crowded row leaves zeros behind (its next user is the next row's histogram, behind barrier 1)
+                for (int w = 0; w < W; ++w) {
+                    hw[w] = H[t * W + w];
+                    sum += hw[w];                                     // both halves at once: no half exceeds 16384
+                    ov |= hw[w] + (u32)(0x7FFF - CAP) * 0x10001u;     // bit 15 / 31 set iff that counter > CAP
+                }
+                const u32 run = (sum & 0xFFFFu) + (sum >> 16);
+                const u32 incl = rb_wave_incl_scan(run);
+                const bool wover = __ballot((ov & 0x80008000u) != 0) != 0;
+                if (lane == 63) wtot[wave] = incl | (wover ? 0x80000000u : 0u);
+                __syncthreads();                                      // barrier 3
+                u32 base0 = incl - run, anyover = 0;
 #pragma unroll
-            for (int w = 0; w < W; ++w)
-                H[t * W + w] = go ? ((base0 + ex[2 * w]) | ((base0 + ex[2 * w + 1]) << 16)) : 0u;
-            if (t == NT - 1) H[NB / 2] = (u32)n;                      // base of the bucket past the last one
+                for (int w = 0; w < NW; ++w) {
+                    const u32 x = wtot[w];
+                    anyover |= x >> 31;
+                    base0 += (w < wave) ? (x & 0x7FFFFFFFu) : 0u;
+                }
+                go = !anyover;
+                // a crowded row leaves zeros behind (the next user is the next row's histogram, behind barrier 1)
+#pragma unroll
+                for (int w = 0; w < W; ++w) {
+                    const u32 c0 = hw[w] & 0xFFFFu, c1 = hw[w] >> 16;
+                    H[t * W + w] = go ? (base0 | ((base0 + c0) << 16)) : 0u;
+                    base0 += c0 + c1;
+                }
+                if (t == NT - 1) H[NB / 2] = base0;                   // = number of non-NaN keys: base past the last bucket
+            }
+        }
+        if constexpr (DBG == 3) {
+            if (go) {
+                __syncthreads();
+#pragma unroll
+                for (int w = 0; w < W; ++w) H[t * W + w] = 0;
+            }
+            go = false;
         }
         u32 bc[E];
         if (go) {
             __syncthreads();                                          // barrier 4
             // ---- (3) scatter into bucket order ----
+            const u32 nv = H[NB / 2];
+            nn = (u32)n - nv;
 #pragma unroll
             for (int e = 0; e < E; ++e) {
-                bc[e] = 0;
-                if (valid(e)) {
+                bc[e] = RB_NOKEY;
+                if (bs[e] != RB_NOKEY) {
                     const u32 b = bs[e] & 0xFFFFu, slot = bs[e] >> 16;
                     const u32 base = H16[b], end = H16[b + 1];
                     S[base + slot] = k[e];
-                    bc[e] = base | ((end - base) << 16) | (slot << 24);   // base < 2^15, cnt and slot <= CAP < 2^8
+                    bc[e] = base | ((end - base) << 16) | (slot << 24);   // base < 2^15, cnt and slot <= CAP < 255
                 }
             }
+            if (nn && t < RB_PAD) S[nv + t] = __builtin_nan("");    // sentinels behind a row shortened by NaNs
         }
         if (rnext < rows) load_row(rnext, k);                         // next row in flight under the member loop
-        if (t == 0) { nnan_out[r] = go ? 0u : RB_ROW_DEFERRED; rowflag[r] = go ? 0 : 1; }
+        if (t == 0) { nnan_out[r] = (go || DBG) ? 0u : RB_ROW_DEFERRED; rowflag[r] = (go || DBG) ? 0 : 1; }
+        if constexpr (DBG == 4) {
+            if (go) {
+                __syncthreads();
+#pragma unroll
+                for (int w = 0; w < W; ++w) H[t * W + w] = 0;
+            }
+            go = false;
+        }
         if (go) {
             __syncthreads();                                          // barrier 5
             // the histogram is dead until the next row's atomics (behind its barrier 1)
 #pragma unroll
             for (int w = 0; w < W; ++w) H[t * W + w] = 0;
             // ---- (4) rank inside the bucket, fold ----
+            const u32 nv = (u32)n - nn;                               // non-NaN keys of the row
+            const u32 v = nv - 1u;                                    // valid others of a non-NaN target
+            const u32 R2 = v * (v - 1u + 2u * nn);                    // J == 2: 2 * [N v + C(v,2)]  (< 2^30)
 #pragma unroll
             for (int e = 0; e < E; ++e) {
-                if (valid(e)) {
+                if (bc[e] != RB_NOKEY) {
                     const u32 base = bc[e] & 0xFFFFu, cnt = (bc[e] >> 16) & 0xFFu;
                     const double *Sp = S + base;
                     const double x = Sp[bc[e] >> 24];                 // own key (its registers hold the next row)
@@ -217,8 +284,18 @@ __global__ __launch_bounds__(NT) void rank_bucket_kernel(const double *__restric
                             le += (y[u] <= x) ? 1u : 0u;
                         }
                     }
-                    const u32 B = base + less, A = (u32)n - base - le;
-                    band_counts_add<J>(A, B, 0u, (u64)(n - 1), acc[e]);
+                    const u32 B = base + less, A = nv - base - le;
+                    if constexpr (J == 2) {
+                        // 2 * contained_2 = 2 N (v - A - B) + v(v-1) - A(A-1) - B(B-1)   (all terms < 2^30)
+                        u32 q = A * (A - 1u) + B * (B - 1u);
+                        if (nn) q += 2u * nn * (A + B);
+                        acc[e][0] += (u64)(R2 - q);
+                    } else {
+                        u64 a7[JMAX - 1] = {0, 0, 0, 0, 0, 0, 0};
+                        band_counts_add<J>(A, B, nn, (u64)(n - 1), a7);
+#pragma unroll
+                        for (int j = 0; j < J - 1; ++j) acc[e][j] += a7[j];
+                    }
                 }
             }
         }
@@ -230,13 +307,13 @@ __global__ __launch_bounds__(NT) void rank_bucket_kernel(const double *__restric
     for (int e = 0; e < E; ++e)
         if (valid(e)) {
 #pragma unroll
-            for (int j = 0; j < J - 1; ++j) P[(size_t)j * n + t + e * NT] = acc[e][j];
+            for (int j = 0; j < J - 1; ++j) P[(size_t)j * n + t + e * NT] = (J == 2) ? (acc[e][0] >> 1) : acc[e][j];
         }
 }
 
 // ---------------------------------------------------------------------------------------------------
 // Z: out[q][j] (+)= sum_g partial[g][j][i(q)] + fold of the pair-image rows flagged in rowflag.
-// block = 64 targets x 16 slices, LDS tree over the slices.
+// block = 32 targets x 32 slices (of workgroups g, of rows), LDS tree over the slices.
 // ---------------------------------------------------------------------------------------------------
 template <int J>
 __global__ __launch_bounds__(1024) void rank_finalize_kernel(const u64 *__restrict__ partial, int G,
@@ -244,22 +321,30 @@ __global__ __launch_bounds__(1024) void rank_finalize_kernel(const u64 *__restri
                                                              const unsigned char *__restrict__ rowflag, i64 rows, i64 n,
                                                              const i64 *__restrict__ targets, i64 tbegin, i64 m,
                                                              u64 *__restrict__ out, int first) {
-    __shared__ u64 red[16][64];
-    const int x = threadIdx.x & 63, y = threadIdx.x >> 6;
-    const i64 q = (i64)blockIdx.x * 64 + x;
+    __shared__ u64 red[32][33];
+    const int x = threadIdx.x & 31, y = threadIdx.x >> 5;
+    const i64 q = (i64)blockIdx.x * 32 + x;
     const i64 i = (q < m) ? (targets ? targets[q] : tbegin + q) : 0;
+    // any deferred row at all?  (one pass over the flags by the whole block; normally none)
+    int any = 0;
+    for (i64 r = threadIdx.x; r < rows; r += 1024) any |= rowflag[r];
+    any = __syncthreads_or(any);
     u64 acc[JMAX - 1];
 #pragma unroll
     for (int j = 0; j < JMAX - 1; ++j) acc[j] = 0;
     if (q < m) {
-        for (int g = y; g < G; g += 16) {
+        const u64 *p = partial + i;
+#pragma unroll 8
+        for (int g = y; g < G; g += 32) {
 #pragma unroll
-            for (int j = 0; j < J - 1; ++j) acc[j] += partial[((size_t)g * (J - 1) + j) * n + i];
+            for (int j = 0; j < J - 1; ++j) acc[j] += p[((size_t)g * (J - 1) + j) * n];
         }
-        for (i64 r = y; r < rows; r += 16) {
-            if (rowflag[r]) {
-                const u32 ab = AB[r * n + i];
-                if (ab != RB_AB_SPECIAL) band_counts_add<J>(ab >> 16, ab & 0xFFFFu, nnan[r], (u64)(n - 1), acc);
+        if (any) {
+            for (i64 r = y; r < rows; r += 32) {
+                if (rowflag[r]) {
+                    const u32 ab = AB[r * n + i];
+                    if (ab != RB_AB_SPECIAL) band_counts_add<J>(ab >> 16, ab & 0xFFFFu, nnan[r], (u64)(n - 1), acc);
+                }
             }
         }
     }
@@ -270,7 +355,7 @@ __global__ __launch_bounds__(1024) void rank_finalize_kernel(const u64 *__restri
         if (y == 0 && q < m) {
             u64 tot = 0;
 #pragma unroll
-            for (int k = 0; k < 16; ++k) tot += red[k][x];
+            for (int k = 0; k < 32; ++k) tot += red[k][x];
             if (first) out[q * (J - 1) + j] = tot;
             else out[q * (J - 1) + j] += tot;
         }
@@ -307,6 +392,16 @@ static int launch_bucket_cfg(const double *Y, i64 n, i64 row0, i64 rows, u64 *pa
                              int G, hipStream_t s) {
     using C = RBCfg<NT, E, LNB>;
     auto kf = rank_bucket_kernel<NT, E, LNB, J, 40, 4>;
+    if constexpr (E == 10 && J == 2) {
+        if (const char *d = getenv("SD_RB_DBG")) {
+            switch (atoi(d)) {
+                case 1: kf = rank_bucket_kernel<NT, E, LNB, J, 40, 4, 1>; break;
+                case 2: kf = rank_bucket_kernel<NT, E, LNB, J, 40, 4, 2>; break;
+                case 3: kf = rank_bucket_kernel<NT, E, LNB, J, 40, 4, 3>; break;
+                case 4: kf = rank_bucket_kernel<NT, E, LNB, J, 40, 4, 4>; break;
+            }
+        }
+    }
     const size_t lds = C::lds_bytes((int)n);
     if (lds > 163840) return fail(SD_ERR_UNSUPPORTED, "bucket kernel: %zu bytes of LDS for n=%lld", lds, (long long)n);
     SD_HIP(hipFuncSetAttribute((const void *)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -346,7 +441,7 @@ int launch_rank_bucket(const double *Y, i64 n, i64 row0, i64 rows, int J, u64 *p
 int launch_rank_finalize(const u64 *partial, int G, const u32 *AB, const u32 *nnan, const unsigned char *rowflag,
                          i64 rows, i64 n, const i64 *targets, i64 tbegin, i64 m, int J, u64 *out, int first,
                          hipStream_t s) {
-    dim3 grid((unsigned)((m + 63) / 64));
+    dim3 grid((unsigned)((m + 31) / 32));
     if (J == 2)
         hipLaunchKernelGGL((rank_finalize_kernel<2>), grid, dim3(1024), 0, s, partial, G, AB, nnan, rowflag, rows, n, targets,
                            tbegin, m, out, first);

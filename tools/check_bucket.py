@@ -37,6 +37,12 @@ def case(name, X, J=2, reps=0, oracle_targets=64):
     b, ms3 = run(X, J, 3, reps)
     ok = (a == b).all()
     tg = np.linspace(0, X.shape[1] - 1, oracle_targets).astype(np.int64)
+    if not ok:
+        bad = np.nonzero((a != b).any(axis=1))[0]
+        print("   differing targets:", bad[:20], "of", len(bad))
+        tg = np.unique(np.concatenate([tg, bad[:64]]))
+        w = oracle.mbd_counts(X, bad[:8], J)
+        print("   impl4", a[bad[:8]].ravel(), "\n   impl3", b[bad[:8]].ravel(), "\n   oracle", w.ravel())
     want = oracle.mbd_counts(X, tg, J)
     ok2 = (a[tg] == want).all()
     print(f"{name:40s} T={X.shape[0]:5d} n={X.shape[1]:6d} J={J} vs impl3 {'OK' if ok else 'DIFF'} vs oracle "
@@ -54,7 +60,7 @@ def main():
     good &= case("walk J=3", X, J=3)
     good &= case("ties (0.1)", np.round(X, 1))
     good &= case("heavy ties (integers)", np.round(X, 0))
-    Y = X.copy(); Y[3, 17] = np.nan; Y[5, :40] = np.nan; Y[9, 100] = np.inf; Y[11, 7] = -np.inf
+    Y = X.copy(); Y[3, 17] = np.nan; Y[5, :40] = np.nan; Y[9, 100] = np.inf; Y[11, 7] = -np.inf; Y[12, 5:9] = np.inf; Y[12, 20:23] = -np.inf; Y[12, 30] = np.nan; Y[13, :] = np.nan; Y[14, 1:] = np.nan; Y[15, 2:] = np.inf
     good &= case("NaN / inf rows", Y)
     Y = X.copy(); Y[4, :] = 1.25; Y[6, :] = 0.0
     good &= case("constant rows", Y)
