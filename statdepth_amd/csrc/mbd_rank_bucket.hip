@@ -33,7 +33,6 @@ namespace sd {
 constexpr u32 RB_AB_SPECIAL = 0xFFFFFFFFu;     // same encodings as mbd_rank_ab.hip
 constexpr u32 RB_ROW_DEFERRED = 0xFFFFFFFFu;
 constexpr int RB_PAD = 8;                      // NaN sentinels behind the bucket-ordered keys (never < or <= anything)
-constexpr u32 RB_NOKEY = 0xFFFFFFFFu;          // bs[e] / bc[e]: no curve here, or a NaN
 
 // ---- wave64 cross-lane helpers on DPP (no LDS traffic, no ds_bpermute latency chain) ----
 // row_shr:1,2,4,8 scan inside each row of 16 lanes, then row_bcast:15 / row_bcast:31 carry the row totals up.
@@ -42,14 +41,27 @@ __device__ __forceinline__ u32 rb_dpp(u32 old, u32 v) {
     return (u32)__builtin_amdgcn_update_dpp((int)old, (int)v, CTRL, ROWMASK, 0xF, false);
 }
 
-__device__ __forceinline__ u32 rb_wave_incl_scan(u32 v) {
+__device__ __forceinline__ u32 rb_row_incl_scan(u32 v) {       // inclusive scan inside each row of 16 lanes
     v += rb_dpp<0x111, 0xF>(0u, v);
     v += rb_dpp<0x112, 0xF>(0u, v);
     v += rb_dpp<0x114, 0xF>(0u, v);
     v += rb_dpp<0x118, 0xF>(0u, v);
+    return v;
+}
+
+__device__ __forceinline__ u32 rb_wave_incl_scan(u32 v) {
+    v = rb_row_incl_scan(v);
     v += rb_dpp<0x142, 0xA>(0u, v);
     v += rb_dpp<0x143, 0xC>(0u, v);
     return v;
+}
+
+__device__ __forceinline__ u32 rb_readlane(u32 v, int l) { return (u32)__builtin_amdgcn_readlane((int)v, l); }
+
+__device__ __forceinline__ double rb_readlane_f64(double v, int l) {
+    const u64 b = (u64)__double_as_longlong(v);
+    const u64 r = (u64)rb_readlane((u32)b, l) | ((u64)rb_readlane((u32)(b >> 32), l) << 32);
+    return __longlong_as_double((long long)r);
 }
 
 template <int CTRL, int ROWMASK, bool MAX>
@@ -60,65 +72,75 @@ __device__ __forceinline__ double rb_mm_step(double v) {
     return MAX ? (o > v ? o : v) : (o < v ? o : v);
 }
 
-// min (or max) over the wave, valid in lane 63
-template <bool MAX>
-__device__ __forceinline__ double rb_wave_minmax_last(double v) {
+// min (or max) over each row of 16 lanes, valid in the row's last lane; ROWS = true carries on to lane 63
+template <bool MAX, bool ROWS>
+__device__ __forceinline__ double rb_minmax_last(double v) {
     v = rb_mm_step<0x111, 0xF, MAX>(v);
     v = rb_mm_step<0x112, 0xF, MAX>(v);
     v = rb_mm_step<0x114, 0xF, MAX>(v);
     v = rb_mm_step<0x118, 0xF, MAX>(v);
-    v = rb_mm_step<0x142, 0xA, MAX>(v);
-    v = rb_mm_step<0x143, 0xC, MAX>(v);
+    if constexpr (ROWS) {
+        v = rb_mm_step<0x142, 0xA, MAX>(v);
+        v = rb_mm_step<0x143, 0xC, MAX>(v);
+    }
     return v;
 }
 
-template <int NT, int E, int LNB>
+template <int NT, int E, int LNB, int U2>
 struct RBCfg {
     static constexpr int NB = 1 << LNB;
     static constexpr int NW = NT / 64;
     static constexpr int W = NB / 2 / NT;                       // histogram words per thread in the prefix sum
-    static_assert(W >= 1, "at least one histogram word per thread");
-    static __host__ __device__ constexpr size_t keys_slots(int n) { return (size_t)((n + RB_PAD + 1) & ~1); }
+    static constexpr int QW = W / 4;                            // ... as 16-byte quads
+    static_assert(W >= 4 && W % 4 == 0, "whole quads of histogram words per thread");
+    static_assert(NW == 16, "cross-wave reductions are laid out for 16 waves");
+    // positions: [0, n) keys, [n, n + RB_PAD) sentinels, DUMMY.. a scratch pair range for keys that are NaN
+    static __host__ __device__ constexpr int dummy_pos(int n) { return (n + RB_PAD + 1) & ~1; }
+    static __host__ __device__ constexpr size_t keys_slots(int n) { return (size_t)dummy_pos(n) + 2 * U2 + 2; }
     static __host__ __device__ constexpr size_t lds_bytes(int n) {
-        return keys_slots(n) * 8 + (size_t)(NB / 2 + 2) * 4 + (size_t)4 * NW * 8 + (size_t)NW * 4 + 16;
+        return keys_slots(n) * 8 + (size_t)(NB / 2 + 4) * 4 + (size_t)4 * NW * 8 + (size_t)NW * 4 + 16;
     }
 };
 
 // DBG (timing experiments only, results invalid): 1 = stop after the range, 2 = after the histogram, 3 = after the
 // prefix sum, 4 = after the scatter
-template <int NT, int E, int LNB, int J, int CAP, int U, int DBG = 0>
+template <int NT, int E, int LNB, int J, int CAP, int U2, int DBG = 0>
 __global__ __launch_bounds__(NT) void rank_bucket_kernel(const double *__restrict__ Y, i64 n64, i64 row0, i64 rows,
                                                          u64 *__restrict__ partial, u32 *__restrict__ nnan_out,
                                                          unsigned char *__restrict__ rowflag) {
-    using C = RBCfg<NT, E, LNB>;
-    constexpr int NB = C::NB, NW = C::NW, W = C::W;
-    static_assert(U >= 1 && U - 1 <= RB_PAD, "member loop reads at most RB_PAD keys past the end");
+    using C = RBCfg<NT, E, LNB, U2>;
+    constexpr int NB = C::NB, NW = C::NW, QW = C::QW;
+    static_assert(2 * U2 - 1 <= RB_PAD, "the first member pass reads at most RB_PAD keys past the end");
     static_assert(CAP < 255 && NB <= 32768, "packing of (base, count, slot)");
     constexpr int NACC = (J == 2) ? 1 : (J - 1);
     extern __shared__ double Sm[];
     const int n = (int)n64;
-    double *S = Sm;                                                   // keys in bucket order + sentinels
+    double *S = Sm;                                                   // keys in bucket order + sentinels + dummy
     u32 *H = reinterpret_cast<u32 *>(S + C::keys_slots(n));           // NB packed u16 counters, then bases
-    double *red = reinterpret_cast<double *>(H + NB / 2 + 2);         // [2][NW][2] min/max partials
+    double *red = reinterpret_cast<double *>(H + NB / 2 + 4);         // [2][NW][2] min/max partials
     u32 *wtot = reinterpret_cast<u32 *>(red + 4 * NW);                // [NW]
     const unsigned short *H16 = reinterpret_cast<const unsigned short *>(H);
     const int t0 = threadIdx.x;
     const double INF = __builtin_huge_val();
+    const double QNAN = __builtin_nan("");
+    const int DUMMY = C::dummy_pos(n);
     int t = t0;
 
-    // one-time LDS setup: sentinels, empty histogram
-    if (t < RB_PAD) S[n + t] = __builtin_nan("");
+    // one-time LDS setup: sentinels + dummy range, empty histogram
+    for (int p = n + t; p < (int)C::keys_slots(n); p += NT) S[p] = QNAN;
+    {
+        uint4 *Hq = reinterpret_cast<uint4 *>(H);
 #pragma unroll
-    for (int w = 0; w < W; ++w) H[t * W + w] = 0;
-    if (t < 2) H[NB / 2 + t] = 0;
+        for (int i = 0; i < QW; ++i) Hq[i * NT + t] = make_uint4(0, 0, 0, 0);
+        if (t < 4) H[NB / 2 + t] = 0;
+    }
 
-    // the host picks E = ceil(n / NT): only the last of a thread's E curves can lie beyond n
-    auto valid = [&](int e) { return e < E - 1 || t + (E - 1) * NT < n; };
+    // curves of thread t: t, t + NT, ...; slots beyond n read as NaN and are treated like any other NaN
     double k[E];
-    auto load_row = [&](i64 r, double (&dst)[E]) {
+    auto load_row = [&](i64 r) {
         const double *rp = Y + (row0 + r) * n + t;
 #pragma unroll
-        for (int e = 0; e < E; ++e) dst[e] = valid(e) ? rp[e * NT] : __builtin_nan("");
+        for (int e = 0; e < E; ++e) k[e] = (e < E - 1 || t + (E - 1) * NT < n) ? rp[e * NT] : QNAN;
     };
     // J == 2: acc[e][0] = 2 * (sum of band counts) (one accumulator, see the fold below); else acc[e][j-2]
     u64 acc[E][NACC];
@@ -127,7 +149,7 @@ __global__ __launch_bounds__(NT) void rank_bucket_kernel(const double *__restric
 #pragma unroll
         for (int j = 0; j < NACC; ++j) acc[e][j] = 0;
 
-    if ((i64)blockIdx.x < rows) load_row(blockIdx.x, k);
+    if ((i64)blockIdx.x < rows) load_row(blockIdx.x);
     int par = 0;
     for (i64 r = blockIdx.x; r < rows; r += gridDim.x) {
         const i64 rnext = r + gridDim.x;
@@ -136,161 +158,203 @@ __global__ __launch_bounds__(NT) void rank_bucket_kernel(const double *__restric
         // and spilling the accumulators to make room (same device as in mbd_rank_ab.hip).
         t = t0;
         asm volatile("" : "+v"(t));
-        const int lane = t & 63, wave = t >> 6;
-        // ---- (0) range of the finite values of the row (NaN: pandas skipna, _containment.py:68-69) ----
+        const int lane = t & 63;
+        const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+        // ---- (0) range of the row.  NaN never wins a comparison (pandas skipna, _containment.py:68-69) ----
         double mn = INF, mx = -INF;
 #pragma unroll
         for (int e = 0; e < E; ++e) {
-            const double x = k[e];                                    // slots beyond n hold NaN
-            const bool fin = __builtin_fabs(x) < INF;
-            mn = (fin && x < mn) ? x : mn;
-            mx = (fin && x > mx) ? x : mx;
+            const double x = k[e];
+            mn = x < mn ? x : mn;
+            mx = x > mx ? x : mx;
         }
-        mn = rb_wave_minmax_last<false>(mn);
-        mx = rb_wave_minmax_last<true>(mx);
+        mn = rb_minmax_last<false, true>(mn);
+        mx = rb_minmax_last<true, true>(mx);
         double *redp = red + par * 2 * NW;
         if (lane == 63) { redp[2 * wave] = mn; redp[2 * wave + 1] = mx; }
         par ^= 1;
         __syncthreads();                                              // barrier 1 (histogram is zero, S is free)
-        double lo = INF, hi = -INF;
-#pragma unroll
-        for (int w = 0; w < NW; ++w) {
-            const double a = redp[2 * w], b = redp[2 * w + 1];
-            lo = a < lo ? a : lo;
-            hi = b > hi ? b : hi;
+        double lo, hi;
+        {
+            const double2 p = reinterpret_cast<const double2 *>(redp)[lane & 15];
+            lo = rb_readlane_f64(rb_minmax_last<false, false>(p.x), 15);
+            hi = rb_readlane_f64(rb_minmax_last<true, false>(p.y), 15);
         }
         const double scale = (double)NB / (hi - lo);                  // range overflow -> 0 -> one crowded bucket
         // Every decision below is block-uniform.  The next row is loaded at ONE place (two load sites would
-        // keep two copies of the key registers alive across the loop).
-        bool go = (hi > lo) && (scale < INF);                         // else: all finite values equal, or none
+        // keep two copies of the key registers alive across the loop).  A row with an infinity, with all its
+        // values equal or with none goes to the search kernel.
+        bool go = (hi > lo) && (scale < INF) && (lo > -INF) && (hi < INF);
         if constexpr (DBG == 1) go = false;
         u32 bs[E];
         u32 nn = 0;                                                   // NaN others of this row (block-uniform)
         if (go) {
-            // ---- (1) bucket + slot.  clamp(fl(fl(x - lo) * scale)) is non-decreasing in x; -inf and +inf
-            //      land in the first and last bucket ----
+            // ---- (1) bucket + slot, branch-free.  min(fl(fl(x - lo) * scale), NB-1) is non-decreasing in x;
+            //      NaNs count into a dummy word behind the histogram ----
 #pragma unroll
             for (int e = 0; e < E; ++e) {
-                bs[e] = RB_NOKEY;
                 const double x = k[e];
-                if (x == x) {
-                    double u = (x - lo) * scale;
-                    u = u > 0.0 ? u : 0.0;
-                    u = u < (double)(NB - 1) ? u : (double)(NB - 1);
-                    const u32 b = (u32)u;
-                    const u32 sh = (b & 1u) * 16u;
-                    const u32 old = atomicAdd(&H[b >> 1], 1u << sh);
-                    bs[e] = b | (((old >> sh) & 0xFFFFu) << 16);
-                }
+                double u = (x - lo) * scale;
+                u = u < (double)(NB - 1) ? u : (double)(NB - 1);      // NaN -> NB-1 (overridden below)
+                u32 b = (u32)u;
+                b = (x == x) ? b : (u32)(NB + 2);
+                const u32 sh = (b & 1u) * 16u;
+                const u32 old = atomicAdd(&H[b >> 1], 1u << sh);
+                bs[e] = b | (((old >> sh) & 0xFFFFu) << 16);
             }
             __syncthreads();                                          // barrier 2
+            uint4 *Hq = reinterpret_cast<uint4 *>(H) + wave * (64 * QW);   // this wave's 64*QW quads, quad i*64+lane
             if constexpr (DBG == 2) {
 #pragma unroll
-                for (int w = 0; w < W; ++w) H[t * W + w] = 0;
+                for (int i = 0; i < QW; ++i) Hq[i * 64 + lane] = make_uint4(0, 0, 0, 0);
                 go = false;
             }
             if constexpr (DBG != 2) {
-                // ---- (2) exclusive prefix sum over the counters; a crowded bucket defers the row ----
-                u32 hw[W], sum = 0, ov = 0;
+                // ---- (2) exclusive prefix sum over the counters (conflict-free 16-byte accesses: lane <-> quad);
+                //      a crowded bucket defers the row ----
+                uint4 hq[QW];
+                u32 runq[QW], inclq[QW], offq[QW], ov = 0, wsum = 0;
+                constexpr u32 OVK = (u32)(0x7FFF - CAP) * 0x10001u;   // x + OVK: bit 15 / 31 set iff that counter > CAP
 #pragma unroll
-                for (int w = 0; w < W; ++w) {
-                    hw[w] = H[t * W + w];
-                    sum += hw[w];                                     // both halves at once: no half exceeds 16384
-                    ov |= hw[w] + (u32)(0x7FFF - CAP) * 0x10001u;     // bit 15 / 31 set iff that counter > CAP
+                for (int i = 0; i < QW; ++i) {
+                    hq[i] = Hq[i * 64 + lane];
+                    const u32 s4 = hq[i].x + hq[i].y + hq[i].z + hq[i].w;   // both halves at once: no half exceeds 16384
+                    ov |= (hq[i].x + OVK) | (hq[i].y + OVK) | (hq[i].z + OVK) | (hq[i].w + OVK);
+                    runq[i] = (s4 & 0xFFFFu) + (s4 >> 16);
+                    inclq[i] = rb_wave_incl_scan(runq[i]);
+                    offq[i] = wsum;
+                    wsum += rb_readlane(inclq[i], 63);
                 }
-                const u32 run = (sum & 0xFFFFu) + (sum >> 16);
-                const u32 incl = rb_wave_incl_scan(run);
                 const bool wover = __ballot((ov & 0x80008000u) != 0) != 0;
-                if (lane == 63) wtot[wave] = incl | (wover ? 0x80000000u : 0u);
+                if (lane == 63) wtot[wave] = wsum | (wover ? 0x80000000u : 0u);
                 __syncthreads();                                      // barrier 3
-                u32 base0 = incl - run, anyover = 0;
-#pragma unroll
-                for (int w = 0; w < NW; ++w) {
-                    const u32 x = wtot[w];
-                    anyover |= x >> 31;
-                    base0 += (w < wave) ? (x & 0x7FFFFFFFu) : 0u;
-                }
+                const u32 wt = wtot[lane & 15];
+                const bool anyover = __ballot((wt >> 31) != 0) != 0;
+                const u32 wscan = rb_row_incl_scan(wt & 0x7FFFFFFFu);
+                const u32 woff = wave ? rb_readlane(wscan, wave - 1) : 0u;
                 go = !anyover;
                 // a crowded row leaves zeros behind (the next user is the next row's histogram, behind barrier 1)
 #pragma unroll
-                for (int w = 0; w < W; ++w) {
-                    const u32 c0 = hw[w] & 0xFFFFu, c1 = hw[w] >> 16;
-                    H[t * W + w] = go ? (base0 | ((base0 + c0) << 16)) : 0u;
-                    base0 += c0 + c1;
+                for (int i = 0; i < QW; ++i) {
+                    u32 base = woff + offq[i] + inclq[i] - runq[i];
+                    uint4 o;
+                    o.x = base | ((base + (hq[i].x & 0xFFFFu)) << 16);
+                    base += (hq[i].x & 0xFFFFu) + (hq[i].x >> 16);
+                    o.y = base | ((base + (hq[i].y & 0xFFFFu)) << 16);
+                    base += (hq[i].y & 0xFFFFu) + (hq[i].y >> 16);
+                    o.z = base | ((base + (hq[i].z & 0xFFFFu)) << 16);
+                    base += (hq[i].z & 0xFFFFu) + (hq[i].z >> 16);
+                    o.w = base | ((base + (hq[i].w & 0xFFFFu)) << 16);
+                    base += (hq[i].w & 0xFFFFu) + (hq[i].w >> 16);
+                    Hq[i * 64 + lane] = go ? o : make_uint4(0, 0, 0, 0);
+                    // base past the last bucket = number of non-NaN keys
+                    if (i == QW - 1 && t == NT - 1) H[NB / 2] = base;
                 }
-                if (t == NT - 1) H[NB / 2] = base0;                   // = number of non-NaN keys: base past the last bucket
             }
         }
         if constexpr (DBG == 3) {
             if (go) {
                 __syncthreads();
+                uint4 *Hq = reinterpret_cast<uint4 *>(H) + wave * (64 * QW);
 #pragma unroll
-                for (int w = 0; w < W; ++w) H[t * W + w] = 0;
+                for (int i = 0; i < QW; ++i) Hq[i * 64 + lane] = make_uint4(0, 0, 0, 0);
             }
             go = false;
         }
-        u32 bc[E];
+        u32 bc[E];                                                    // base | count << 16 | slot << 24; count 0: NaN
         if (go) {
             __syncthreads();                                          // barrier 4
-            // ---- (3) scatter into bucket order ----
+            // ---- (3) scatter into bucket order (branch-free; NaNs write the dummy slot) ----
             const u32 nv = H[NB / 2];
             nn = (u32)n - nv;
 #pragma unroll
             for (int e = 0; e < E; ++e) {
-                bc[e] = RB_NOKEY;
-                if (bs[e] != RB_NOKEY) {
-                    const u32 b = bs[e] & 0xFFFFu, slot = bs[e] >> 16;
-                    const u32 base = H16[b], end = H16[b + 1];
-                    S[base + slot] = k[e];
-                    bc[e] = base | ((end - base) << 16) | (slot << 24);   // base < 2^15, cnt and slot <= CAP < 255
-                }
+                const u32 b = bs[e] & 0xFFFFu, slot = bs[e] >> 16;
+                const u32 base = H16[b], end = H16[b + 1];
+                const bool isk = b < (u32)NB;
+                S[isk ? base + slot : (u32)DUMMY] = k[e];
+                bc[e] = isk ? (base | ((end - base) << 16) | (slot << 24)) : (u32)DUMMY;
             }
-            if (nn && t < RB_PAD) S[nv + t] = __builtin_nan("");    // sentinels behind a row shortened by NaNs
+            if (nn && t < RB_PAD) S[nv + t] = QNAN;                   // sentinels behind a row shortened by NaNs
         }
-        if (rnext < rows) load_row(rnext, k);                         // next row in flight under the member loop
+        if (rnext < rows) load_row(rnext);                            // next row in flight under the member passes
         if (t == 0) { nnan_out[r] = (go || DBG) ? 0u : RB_ROW_DEFERRED; rowflag[r] = (go || DBG) ? 0 : 1; }
         if constexpr (DBG == 4) {
             if (go) {
                 __syncthreads();
+                uint4 *Hq = reinterpret_cast<uint4 *>(H) + wave * (64 * QW);
 #pragma unroll
-                for (int w = 0; w < W; ++w) H[t * W + w] = 0;
+                for (int i = 0; i < QW; ++i) Hq[i * 64 + lane] = make_uint4(0, 0, 0, 0);
             }
             go = false;
         }
         if (go) {
             __syncthreads();                                          // barrier 5
             // the histogram is dead until the next row's atomics (behind its barrier 1)
+            {
+                uint4 *Hq = reinterpret_cast<uint4 *>(H) + wave * (64 * QW);
 #pragma unroll
-            for (int w = 0; w < W; ++w) H[t * W + w] = 0;
-            // ---- (4) rank inside the bucket, fold ----
+                for (int i = 0; i < QW; ++i) Hq[i * 64 + lane] = make_uint4(0, 0, 0, 0);
+            }
+            // ---- (4) rank inside the bucket.  First pass, branch-free: 2*U2 keys from the even position at or
+            //      below the bucket's base (16-byte reads); a key in front of an odd base belongs to an earlier
+            //      bucket, compares below, and is taken off again.  Second pass: the rest of longer buckets. ----
+            u32 pk[E];                                                // less | le << 16
+            bool more = false;
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const u32 base = bc[e] & 0xFFFFu, cnt = (bc[e] >> 16) & 0xFFu, slot = bc[e] >> 24;
+                const u32 odd = base & 1u;
+                const double x = S[base + slot];                      // own key (its registers hold the next row)
+                const double2 *Sq = reinterpret_cast<const double2 *>(S + (base - odd));
+                u32 less = 0, le = 0;
+#pragma unroll
+                for (int u = 0; u < U2; ++u) {
+                    const double2 y = Sq[u];
+                    less += (y.x < x) ? 1u : 0u;
+                    le += (y.x <= x) ? 1u : 0u;
+                    less += (y.y < x) ? 1u : 0u;
+                    le += (y.y <= x) ? 1u : 0u;
+                }
+                pk[e] = (less - odd) | ((le - odd) << 16);
+                more |= cnt + odd > (u32)(2 * U2);
+            }
+            if (__ballot(more) != 0) {
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    const u32 base = bc[e] & 0xFFFFu, cnt = (bc[e] >> 16) & 0xFFu, slot = bc[e] >> 24;
+                    const u32 odd = base & 1u;
+                    if (cnt + odd > (u32)(2 * U2)) {
+                        const double x = S[base + slot];
+                        const double2 *Sq = reinterpret_cast<const double2 *>(S + (base - odd));
+                        u32 less = 0, le = 0;
+#pragma unroll 1
+                        for (u32 kk = 2 * U2; kk < cnt + odd; kk += 2) {
+                            const double2 y = Sq[kk >> 1];
+                            less += (y.x < x) ? 1u : 0u;
+                            le += (y.x <= x) ? 1u : 0u;
+                            less += (y.y < x) ? 1u : 0u;
+                            le += (y.y <= x) ? 1u : 0u;
+                        }
+                        pk[e] += less | (le << 16);
+                    }
+                }
+            }
+            // ---- fold ----
             const u32 nv = (u32)n - nn;                               // non-NaN keys of the row
             const u32 v = nv - 1u;                                    // valid others of a non-NaN target
             const u32 R2 = v * (v - 1u + 2u * nn);                    // J == 2: 2 * [N v + C(v,2)]  (< 2^30)
 #pragma unroll
             for (int e = 0; e < E; ++e) {
-                if (bc[e] != RB_NOKEY) {
-                    const u32 base = bc[e] & 0xFFFFu, cnt = (bc[e] >> 16) & 0xFFu;
-                    const double *Sp = S + base;
-                    const double x = Sp[bc[e] >> 24];                 // own key (its registers hold the next row)
-                    u32 less = 0, le = 0;
-#pragma unroll 1
-                    for (u32 kk = 0; kk < cnt; kk += U) {
-                        double y[U];
-#pragma unroll
-                        for (int u = 0; u < U; ++u) y[u] = Sp[kk + u];
-#pragma unroll
-                        for (int u = 0; u < U; ++u) {
-                            less += (y[u] < x) ? 1u : 0u;
-                            le += (y[u] <= x) ? 1u : 0u;
-                        }
-                    }
-                    const u32 B = base + less, A = nv - base - le;
-                    if constexpr (J == 2) {
-                        // 2 * contained_2 = 2 N (v - A - B) + v(v-1) - A(A-1) - B(B-1)   (all terms < 2^30)
-                        u32 q = A * (A - 1u) + B * (B - 1u);
-                        if (nn) q += 2u * nn * (A + B);
-                        acc[e][0] += (u64)(R2 - q);
-                    } else {
+                const u32 base = bc[e] & 0xFFFFu, cnt = (bc[e] >> 16) & 0xFFu;
+                const u32 B = base + (pk[e] & 0xFFFFu), A = nv - base - (pk[e] >> 16);
+                if constexpr (J == 2) {
+                    // 2 * contained_2 = 2 N (v - A - B) + v(v-1) - A(A-1) - B(B-1)   (all terms < 2^30)
+                    u32 q = __umul24(A, A - 1u) + __umul24(B, B - 1u);   // A, B < 2^15: 24-bit multiplies are exact
+                    if (nn) q += 2u * __umul24(nn, A + B);
+                    acc[e][0] += (u64)(cnt ? R2 - q : 0u);
+                } else {
+                    if (cnt) {
                         u64 a7[JMAX - 1] = {0, 0, 0, 0, 0, 0, 0};
                         band_counts_add<J>(A, B, nn, (u64)(n - 1), a7);
 #pragma unroll
@@ -305,7 +369,7 @@ __global__ __launch_bounds__(NT) void rank_bucket_kernel(const double *__restric
     u64 *P = partial + (size_t)blockIdx.x * (J - 1) * n;
 #pragma unroll
     for (int e = 0; e < E; ++e)
-        if (valid(e)) {
+        if (e < E - 1 || t + (E - 1) * NT < n) {
 #pragma unroll
             for (int j = 0; j < J - 1; ++j) P[(size_t)j * n + t + e * NT] = (J == 2) ? (acc[e][0] >> 1) : acc[e][j];
         }
@@ -387,18 +451,22 @@ size_t mbd_rank_bucket_workspace_bytes(i64 rows, i64 n, int J) {
     return align_up((size_t)mbd_rank_bucket_max_grid() * (J - 1) * n * 8, 256) + align_up((size_t)rows, 256) + 512;
 }
 
+#ifndef RB_U2
+#define RB_U2 3
+#endif
 template <int NT, int E, int LNB, int J>
 static int launch_bucket_cfg(const double *Y, i64 n, i64 row0, i64 rows, u64 *partial, u32 *nnan, unsigned char *rowflag,
                              int G, hipStream_t s) {
-    using C = RBCfg<NT, E, LNB>;
-    auto kf = rank_bucket_kernel<NT, E, LNB, J, 40, 4>;
+    constexpr int U2 = RB_U2;
+    using C = RBCfg<NT, E, LNB, U2>;
+    auto kf = rank_bucket_kernel<NT, E, LNB, J, 40, U2>;
     if constexpr (E == 10 && J == 2) {
         if (const char *d = getenv("SD_RB_DBG")) {
             switch (atoi(d)) {
-                case 1: kf = rank_bucket_kernel<NT, E, LNB, J, 40, 4, 1>; break;
-                case 2: kf = rank_bucket_kernel<NT, E, LNB, J, 40, 4, 2>; break;
-                case 3: kf = rank_bucket_kernel<NT, E, LNB, J, 40, 4, 3>; break;
-                case 4: kf = rank_bucket_kernel<NT, E, LNB, J, 40, 4, 4>; break;
+                case 1: kf = rank_bucket_kernel<NT, E, LNB, J, 40, U2, 1>; break;
+                case 2: kf = rank_bucket_kernel<NT, E, LNB, J, 40, U2, 2>; break;
+                case 3: kf = rank_bucket_kernel<NT, E, LNB, J, 40, U2, 3>; break;
+                case 4: kf = rank_bucket_kernel<NT, E, LNB, J, 40, U2, 4>; break;
             }
         }
     }
@@ -410,13 +478,16 @@ static int launch_bucket_cfg(const double *Y, i64 n, i64 row0, i64 rows, u64 *pa
     return SD_OK;
 }
 
+#ifndef RB_LNB_SMALL
+#define RB_LNB_SMALL 14
+#endif
 template <int J>
 static int launch_bucket_j(const double *Y, i64 n, i64 row0, i64 rows, u64 *partial, u32 *nnan, unsigned char *rowflag,
                            int G, hipStream_t s) {
     // E = ceil(n / 1024); 16384 buckets while keys + histogram fit the 160 KiB of LDS, 8192 above
     switch ((int)((n + 1023) / 1024)) {
-        case 9: return launch_bucket_cfg<1024, 9, 14, J>(Y, n, row0, rows, partial, nnan, rowflag, G, s);
-        case 10: return launch_bucket_cfg<1024, 10, 14, J>(Y, n, row0, rows, partial, nnan, rowflag, G, s);
+        case 9: return launch_bucket_cfg<1024, 9, RB_LNB_SMALL, J>(Y, n, row0, rows, partial, nnan, rowflag, G, s);
+        case 10: return launch_bucket_cfg<1024, 10, RB_LNB_SMALL, J>(Y, n, row0, rows, partial, nnan, rowflag, G, s);
         case 11: return launch_bucket_cfg<1024, 11, 14, J>(Y, n, row0, rows, partial, nnan, rowflag, G, s);
         case 12: return launch_bucket_cfg<1024, 12, 14, J>(Y, n, row0, rows, partial, nnan, rowflag, G, s);
         case 13: return launch_bucket_cfg<1024, 13, 14, J>(Y, n, row0, rows, partial, nnan, rowflag, G, s);
