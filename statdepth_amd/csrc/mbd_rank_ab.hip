@@ -381,6 +381,7 @@ static int ab_grid(i64 rows, int per_cu = 1) {
 
 static i64 ab_rows_per_batch(i64 T, i64 n) {
     i64 r = ((i64)1 << 30) / (n * 4);       // pair image <= 1 GiB
+    if (r > 65536) r = 65536;               // and the bucket kernel's per-workgroup bitmap of set-aside rows (2048 bits)
     if (const char *e = getenv("SD_RANK_ROWS_PER_BATCH")) {   // tests: force several batches on small inputs
         i64 v = atoll(e);
         if (v > 0 && v < r) r = v;
@@ -476,7 +477,8 @@ int launch_mbd_rank(const double *Y, i64 T, i64 n, const i64 *targets, i64 tbegi
         if (impl == 4 && (rc = launch_rank_bucket(Y, n, row0, rows, J, partial, nnan, rowflag, &G, s))) return rc;
         // E = 16 keys per thread throughout; smaller rows take smaller workgroups so that several rows are in
         // flight per CU (n = 4000: 4 workgroups of 256 threads per CU, 0.053 ms against 0.091 ms for 1024 x 4)
-        if (n <= 1024) rc = launch_sorts<64, 16>(Y, n, row0, rows, AB, nnan, impl, s);
+        if (impl == 4) rc = SD_OK;
+        else if (n <= 1024) rc = launch_sorts<64, 16>(Y, n, row0, rows, AB, nnan, impl, s);
         else if (n <= 2048) rc = launch_sorts<128, 16>(Y, n, row0, rows, AB, nnan, impl, s);
         else if (n <= 4096) rc = launch_sorts<256, 16>(Y, n, row0, rows, AB, nnan, impl, s);
         else if (n <= 8192) rc = launch_sorts<512, 16>(Y, n, row0, rows, AB, nnan, impl, s);
@@ -484,8 +486,9 @@ int launch_mbd_rank(const double *Y, i64 T, i64 n, const i64 *targets, i64 tbegi
         if (rc) return rc;
         dim3 grid((unsigned)((m + 63) / 64));
         const int first = row0 == 0;
-        if (impl == 4) {
-            if ((rc = launch_rank_finalize(partial, G, AB, nnan, rowflag, rows, n, targets, tbegin, m, J, out, first, s)))
+        if (impl == 4) {   // the bucket kernel ranked every row itself: no pair image, no search launch
+            if ((rc = launch_rank_finalize(partial, G, nullptr, nullptr, nullptr, rows, n, targets, tbegin, m, J, out,
+                                           first, s)))
                 return rc;
             continue;
         }

@@ -27,6 +27,7 @@
 #include <stdlib.h>
 
 #include "sd_common.h"
+#include "rank_sort.h"
 
 namespace sd {
 
@@ -86,6 +87,70 @@ __device__ __forceinline__ double rb_minmax_last(double v) {
     return v;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// The row the bucket map cannot spread (an infinity, all values equal, a crowded bucket): in-LDS sort of the
+// plain values + binary search, the method of rank_search_kernel (mbd_rank_ab.hip), for ONE row inside the
+// bucket kernel, run behind the main row loop for the rows it set aside.  Thread t gets the pairs
+// of its curves t + 1024 e in ab[e] (B | A << 16, RB_AB_SPECIAL where the curve is NaN or beyond n).
+// The sort image overlays the LDS at Sm; s_cnt is one LDS word outside it.
+// ---------------------------------------------------------------------------------------------------
+constexpr int RB_SNT = 1024, RB_SE = 16;
+__device__ __forceinline__ void rb_slow_row(const double *__restrict__ row, int n, double *Sm, u32 *s_cnt, u32 *ab,
+                                         u32 *nnan_out) {
+    using SC = R2Cfg<RB_SNT, RB_SE>;
+    using Sorter = R2Sorter<RB_SNT, RB_SE>;
+    constexpr int N = SC::N, LE = SC::LE, WB = SC::WB;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int n_act = ((n + WB - 1) / WB) * WB;
+    const bool wreal = wave * WB < n_act;
+    const double INF = __builtin_huge_val();
+    if (t == 0) *s_cnt = 0;
+    __syncthreads();
+    double k[RB_SE];
+    u32 mynan = 0;
+    if (wreal) {
+        const int i0 = wave * WB + lane;
+#pragma unroll
+        for (int e = 0; e < RB_SE; ++e) {
+            double x = (i0 + e * 64 < n) ? row[i0 + e * 64] : INF;
+            const bool isn = x != x;                                  // NaN -> +inf, counted (pandas skipna)
+            mynan += isn ? 1u : 0u;
+            k[e] = isn ? INF : x;
+        }
+    }
+    if (mynan) atomicAdd(s_cnt, mynan);
+    Sorter::sort(k, Sm, t, n_act, wreal, INF);
+    if (wreal) {
+        double *Sw = Sm + r2_base<0, LE>(t);
+#pragma unroll
+        for (int e = 0; e < RB_SE; ++e) Sw[r2_off<0, LE>(e)] = k[e];
+    }
+    __syncthreads();
+    const u32 nnan = *s_cnt;
+#pragma unroll 4
+    for (int e = 0; e < RB_SE; ++e) {
+        u32 r = RB_AB_SPECIAL;
+        if (t + e * RB_SNT < n) {
+            const double x = row[t + e * RB_SNT];
+            if (x == x) {
+                const int lo = r2_bound<N, SlotPad<LE>, false, false>(Sm, n_act, x, INF);   // x is in the row
+                int hi = lo + 1, step = 1;                            // gallop over the tie run of x
+                while (hi + step <= n_act && Sm[r2_phys<LE>(hi + step - 1)] <= x) { hi += step; step <<= 1; }
+                while (step > 1) {
+                    step >>= 1;
+                    if (hi + step <= n_act && Sm[r2_phys<LE>(hi + step - 1)] <= x) hi += step;
+                }
+                // keys <= x within [0, n_act) are real non-NaN values unless x = +inf
+                const u32 A = (x == INF) ? 0u : (u32)(n - hi) - nnan;
+                r = (u32)lo | (A << 16);
+            }
+        }
+        ab[e] = r;
+    }
+    *nnan_out = nnan;
+    __syncthreads();                                                  // the image is free again
+}
+
 template <int NT, int E, int LNB, int U2>
 struct RBCfg {
     static constexpr int NB = 1 << LNB;
@@ -94,11 +159,17 @@ struct RBCfg {
     static constexpr int QW = W / 4;                            // ... as 16-byte quads
     static_assert(W >= 4 && W % 4 == 0, "whole quads of histogram words per thread");
     static_assert(NW == 16, "cross-wave reductions are laid out for 16 waves");
+    static_assert(NT == RB_SNT, "rb_slow_row is compiled for this workgroup size");
     // positions: [0, n) keys, [n, n + RB_PAD) sentinels, DUMMY.. a scratch pair range for keys that are NaN
     static __host__ __device__ constexpr int dummy_pos(int n) { return (n + RB_PAD + 1) & ~1; }
     static __host__ __device__ constexpr size_t keys_slots(int n) { return (size_t)dummy_pos(n) + 2 * U2 + 2; }
+    static constexpr int DEFW = 64;                              // bitmap of set-aside rows: 2048 rows per workgroup and launch
+    static constexpr size_t HDR = (size_t)4 * NW * 8 + (size_t)NW * 4 + (size_t)DEFW * 4 + 64;   // + min/max partials, wave totals
     static __host__ __device__ constexpr size_t lds_bytes(int n) {
-        return keys_slots(n) * 8 + (size_t)(NB / 2 + 4) * 4 + (size_t)4 * NW * 8 + (size_t)NW * 4 + 16;
+        const size_t a = keys_slots(n) * 8 + (size_t)(NB / 2 + 4) * 4;
+        const size_t n_act = (size_t)((n + 1023) / 1024) * 1024;
+        const size_t b = (n_act + n_act / 16) * 8;                     // sort image of rb_slow_row (R2Cfg<1024,16> slots)
+        return HDR + (a > b ? a : b);
     }
 };
 
@@ -115,10 +186,11 @@ __global__ __launch_bounds__(NT) void rank_bucket_kernel(const double *__restric
     constexpr int NACC = (J == 2) ? 1 : (J - 1);
     extern __shared__ double Sm[];
     const int n = (int)n64;
-    double *S = Sm;                                                   // keys in bucket order + sentinels + dummy
-    u32 *H = reinterpret_cast<u32 *>(S + C::keys_slots(n));           // NB packed u16 counters, then bases
-    double *red = reinterpret_cast<double *>(H + NB / 2 + 4);         // [2][NW][2] min/max partials
+    double *red = Sm;                                                 // [2][NW][2] min/max partials
     u32 *wtot = reinterpret_cast<u32 *>(red + 4 * NW);                // [NW]
+    u32 *defer = wtot + NW;                                           // [DEFW] bitmap of the rows set aside
+    double *S = Sm + C::HDR / 8;                                      // keys in bucket order + sentinels + dummy
+    u32 *H = reinterpret_cast<u32 *>(S + C::keys_slots(n));           // NB packed u16 counters, then bases
     const unsigned short *H16 = reinterpret_cast<const unsigned short *>(H);
     const int t0 = threadIdx.x;
     const double INF = __builtin_huge_val();
@@ -126,14 +198,17 @@ __global__ __launch_bounds__(NT) void rank_bucket_kernel(const double *__restric
     const int DUMMY = C::dummy_pos(n);
     int t = t0;
 
-    // one-time LDS setup: sentinels + dummy range, empty histogram
-    for (int p = n + t; p < (int)C::keys_slots(n); p += NT) S[p] = QNAN;
-    {
+    // LDS setup (once, and again behind rb_slow_row): sentinels + dummy range, empty histogram
+    auto lds_setup = [&]() {
+        for (int p = n + t; p < (int)C::keys_slots(n); p += NT) S[p] = QNAN;
         uint4 *Hq = reinterpret_cast<uint4 *>(H);
 #pragma unroll
         for (int i = 0; i < QW; ++i) Hq[i * NT + t] = make_uint4(0, 0, 0, 0);
         if (t < 4) H[NB / 2 + t] = 0;
-    }
+    };
+    lds_setup();
+    if (t < C::DEFW) defer[t] = 0;
+    u32 ndefer = 0, rowidx = 0;                                       // block-uniform
 
     // curves of thread t: t, t + NT, ...; slots beyond n read as NaN and are treated like any other NaN
     double k[E];
@@ -261,6 +336,13 @@ __global__ __launch_bounds__(NT) void rank_bucket_kernel(const double *__restric
             }
             go = false;
         }
+        if constexpr (DBG == 0) {
+            if (!go) {                                                // set aside: sorted behind the loop
+                if (t == 0) defer[rowidx >> 5] |= 1u << (rowidx & 31);
+                ++ndefer;
+            }
+        }
+        ++rowidx;
         u32 bc[E];                                                    // base | count << 16 | slot << 24; count 0: NaN
         if (go) {
             __syncthreads();                                          // barrier 4
@@ -278,7 +360,6 @@ __global__ __launch_bounds__(NT) void rank_bucket_kernel(const double *__restric
             if (nn && t < RB_PAD) S[nv + t] = QNAN;                   // sentinels behind a row shortened by NaNs
         }
         if (rnext < rows) load_row(rnext);                            // next row in flight under the member passes
-        if (t == 0) { nnan_out[r] = (go || DBG) ? 0u : RB_ROW_DEFERRED; rowflag[r] = (go || DBG) ? 0 : 1; }
         if constexpr (DBG == 4) {
             if (go) {
                 __syncthreads();
@@ -322,7 +403,9 @@ __global__ __launch_bounds__(NT) void rank_bucket_kernel(const double *__restric
             if (__ballot(more) != 0) {
 #pragma unroll
                 for (int e = 0; e < E; ++e) {
-                    const u32 base = bc[e] & 0xFFFFu, cnt = (bc[e] >> 16) & 0xFFu, slot = bc[e] >> 24;
+                    u32 bce = bc[e];
+                    asm volatile("" : "+v"(bce));                     // unpack again here: nothing kept alive from pass 1
+                    const u32 base = bce & 0xFFFFu, cnt = (bce >> 16) & 0xFFu, slot = bce >> 24;
                     const u32 odd = base & 1u;
                     if (cnt + odd > (u32)(2 * U2)) {
                         const double x = S[base + slot];
@@ -365,6 +448,28 @@ __global__ __launch_bounds__(NT) void rank_bucket_kernel(const double *__restric
         }
     }
     t = t0;
+    // ---- the rows the bucket map could not spread (an infinity, all values equal, a crowded bucket): sort + search ----
+    if (ndefer) {                                                     // block-uniform, cold
+        __syncthreads();
+        rowidx = 0;
+        for (i64 r = blockIdx.x; r < rows; r += gridDim.x, ++rowidx) {
+            if (!((defer[rowidx >> 5] >> (rowidx & 31)) & 1u)) continue;
+            u32 ab[RB_SE], nnan_s;
+            rb_slow_row(Y + (row0 + r) * n, n, S, wtot, ab, &nnan_s);
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                if (ab[e] != RB_AB_SPECIAL) {
+                    u64 a7[JMAX - 1] = {0, 0, 0, 0, 0, 0, 0};
+                    band_counts_add<J>(ab[e] >> 16, ab[e] & 0xFFFFu, nnan_s, (u64)(n - 1), a7);
+                    if constexpr (J == 2) acc[e][0] += 2 * a7[0];
+                    else {
+#pragma unroll
+                        for (int j = 0; j < J - 1; ++j) acc[e][j] += a7[j];
+                    }
+                }
+            }
+        }
+    }
     // ---- this workgroup's partial totals ----
     u64 *P = partial + (size_t)blockIdx.x * (J - 1) * n;
 #pragma unroll
@@ -377,7 +482,8 @@ __global__ __launch_bounds__(NT) void rank_bucket_kernel(const double *__restric
 
 // ---------------------------------------------------------------------------------------------------
 // Z: out[q][j] (+)= sum_g partial[g][j][i(q)] + fold of the pair-image rows flagged in rowflag.
-// block = 32 targets x 32 slices (of workgroups g, of rows), LDS tree over the slices.
+// block = 32 targets x 32 slices (of workgroups g, of rows), LDS tree over the slices.  rowflag == nullptr: no pair image
+// (the bucket kernel ranks every row itself).
 // ---------------------------------------------------------------------------------------------------
 template <int J>
 __global__ __launch_bounds__(1024) void rank_finalize_kernel(const u64 *__restrict__ partial, int G,
@@ -391,8 +497,10 @@ __global__ __launch_bounds__(1024) void rank_finalize_kernel(const u64 *__restri
     const i64 i = (q < m) ? (targets ? targets[q] : tbegin + q) : 0;
     // any deferred row at all?  (one pass over the flags by the whole block; normally none)
     int any = 0;
-    for (i64 r = threadIdx.x; r < rows; r += 1024) any |= rowflag[r];
-    any = __syncthreads_or(any);
+    if (rowflag) {                                                    // block-uniform
+        for (i64 r = threadIdx.x; r < rows; r += 1024) any |= rowflag[r];
+        any = __syncthreads_or(any);
+    }
     u64 acc[JMAX - 1];
 #pragma unroll
     for (int j = 0; j < JMAX - 1; ++j) acc[j] = 0;
@@ -451,17 +559,13 @@ size_t mbd_rank_bucket_workspace_bytes(i64 rows, i64 n, int J) {
     return align_up((size_t)mbd_rank_bucket_max_grid() * (J - 1) * n * 8, 256) + align_up((size_t)rows, 256) + 512;
 }
 
-#ifndef RB_U2
-#define RB_U2 3
-#endif
-template <int NT, int E, int LNB, int J>
+template <int NT, int E, int LNB, int J, int U2>
 static int launch_bucket_cfg(const double *Y, i64 n, i64 row0, i64 rows, u64 *partial, u32 *nnan, unsigned char *rowflag,
                              int G, hipStream_t s) {
-    constexpr int U2 = RB_U2;
     using C = RBCfg<NT, E, LNB, U2>;
     auto kf = rank_bucket_kernel<NT, E, LNB, J, 40, U2>;
-    if constexpr (E == 10 && J == 2) {
-        if (const char *d = getenv("SD_RB_DBG")) {
+    if constexpr (E == 10 && J == 2 && LNB == 14 && U2 == 3) {
+        if (const char *d = getenv("SD_RB_DBG")) {        // timing experiments: truncated kernels
             switch (atoi(d)) {
                 case 1: kf = rank_bucket_kernel<NT, E, LNB, J, 40, U2, 1>; break;
                 case 2: kf = rank_bucket_kernel<NT, E, LNB, J, 40, U2, 2>; break;
@@ -478,23 +582,34 @@ static int launch_bucket_cfg(const double *Y, i64 n, i64 row0, i64 rows, u64 *pa
     return SD_OK;
 }
 
-#ifndef RB_LNB_SMALL
-#define RB_LNB_SMALL 14
-#endif
 template <int J>
 static int launch_bucket_j(const double *Y, i64 n, i64 row0, i64 rows, u64 *partial, u32 *nnan, unsigned char *rowflag,
                            int G, hipStream_t s) {
-    // E = ceil(n / 1024); 16384 buckets while keys + histogram fit the 160 KiB of LDS, 8192 above
-    switch ((int)((n + 1023) / 1024)) {
-        case 9: return launch_bucket_cfg<1024, 9, RB_LNB_SMALL, J>(Y, n, row0, rows, partial, nnan, rowflag, G, s);
-        case 10: return launch_bucket_cfg<1024, 10, RB_LNB_SMALL, J>(Y, n, row0, rows, partial, nnan, rowflag, G, s);
-        case 11: return launch_bucket_cfg<1024, 11, 14, J>(Y, n, row0, rows, partial, nnan, rowflag, G, s);
-        case 12: return launch_bucket_cfg<1024, 12, 14, J>(Y, n, row0, rows, partial, nnan, rowflag, G, s);
-        case 13: return launch_bucket_cfg<1024, 13, 14, J>(Y, n, row0, rows, partial, nnan, rowflag, G, s);
-        case 14: return launch_bucket_cfg<1024, 14, 14, J>(Y, n, row0, rows, partial, nnan, rowflag, G, s);
-        case 15: return launch_bucket_cfg<1024, 15, 14, J>(Y, n, row0, rows, partial, nnan, rowflag, G, s);
-        case 16: return launch_bucket_cfg<1024, 16, 13, J>(Y, n, row0, rows, partial, nnan, rowflag, G, s);
+    // E = ceil(n / 1024); 16384 buckets while keys + histogram fit the 160 KiB of LDS, 8192 above;
+    // first member pass: 3 x 16 bytes
+#define RB_ARGS Y, n, row0, rows, partial, nnan, rowflag, G, s
+    const int E = (int)((n + 1023) / 1024);
+    if (E == 10 && J == 2) {                              // tuning experiments on the config-2 shape
+        const char *eu = getenv("SD_RB_U2"), *el = getenv("SD_RB_LNB");
+        const int u2 = eu ? atoi(eu) : 3, lnb = el ? atoi(el) : 14;
+        if (lnb == 14 && u2 == 2) return launch_bucket_cfg<1024, 10, 14, 2, 2>(RB_ARGS);
+        if (lnb == 14 && u2 == 4) return launch_bucket_cfg<1024, 10, 14, 2, 4>(RB_ARGS);
+        if (lnb == 15 && u2 == 2) return launch_bucket_cfg<1024, 10, 15, 2, 2>(RB_ARGS);
+        if (lnb == 15 && u2 == 3) return launch_bucket_cfg<1024, 10, 15, 2, 3>(RB_ARGS);
+        if (lnb == 13 && u2 == 3) return launch_bucket_cfg<1024, 10, 13, 2, 3>(RB_ARGS);
+        if (lnb == 13 && u2 == 4) return launch_bucket_cfg<1024, 10, 13, 2, 4>(RB_ARGS);
     }
+    switch (E) {
+        case 9: return launch_bucket_cfg<1024, 9, 14, J, 3>(RB_ARGS);
+        case 10: return launch_bucket_cfg<1024, 10, 14, J, 3>(RB_ARGS);
+        case 11: return launch_bucket_cfg<1024, 11, 14, J, 3>(RB_ARGS);
+        case 12: return launch_bucket_cfg<1024, 12, 14, J, 3>(RB_ARGS);
+        case 13: return launch_bucket_cfg<1024, 13, 14, J, 3>(RB_ARGS);
+        case 14: return launch_bucket_cfg<1024, 14, 14, J, 3>(RB_ARGS);
+        case 15: return launch_bucket_cfg<1024, 15, 14, J, 3>(RB_ARGS);
+        case 16: return launch_bucket_cfg<1024, 16, 13, J, 3>(RB_ARGS);
+    }
+#undef RB_ARGS
     return fail(SD_ERR_UNSUPPORTED, "bucket kernel covers 8192 < n <= 16384");
 }
 
@@ -504,6 +619,7 @@ int launch_rank_bucket(const double *Y, i64 n, i64 row0, i64 rows, int J, u64 *p
     const int cus = mbd_rank_bucket_max_grid();
     const int G = (int)(rows < cus ? rows : cus);
     *G_out = G;
+    if (rows > (i64)G * 2048) return fail(SD_ERR_INVALID, "bucket kernel: more than 2048 rows per workgroup in one launch");
     if (J == 2) return launch_bucket_j<2>(Y, n, row0, rows, partial, nnan, rowflag, G, s);
     if (J == 3) return launch_bucket_j<3>(Y, n, row0, rows, partial, nnan, rowflag, G, s);
     return fail(SD_ERR_UNSUPPORTED, "bucket kernel covers J in [2,3]");
