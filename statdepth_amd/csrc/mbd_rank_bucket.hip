@@ -1,4 +1,4 @@
-// mbd_rank_bucket.hip -- K1+K2 rank formulation without a sort (default path of sd_mbd_counts, n <= 16384, J <= 3).
+// mbd_rank_bucket.hip -- K1+K2 rank formulation without a sort (default path of sd_mbd_counts, 2 <= n <= 16384, J <= 3).
 //
 // Same integers as the pairwise kernel and the reference's enumeration (_functional.py:246-251,
 // _containment.py:75-77): per (curve, timepoint) the counts B (others strictly below) and A (strictly above),
@@ -549,7 +549,9 @@ static int rb_cus() {
 
 bool mbd_rank_bucket_supported(i64 T, i64 n, int J) {
     (void)T;
-    return n > 8192 && n <= 16384 && J >= 2 && J <= 3;
+    i64 nmin = 1;                          // measured faster than the sort kernels from n = 600 to 16384
+    if (const char *e = getenv("SD_RB_MIN_N")) nmin = atoll(e);   // tuning experiments
+    return n > nmin && n <= 16384 && J >= 2 && J <= 3;
 }
 
 // upper bound of the grid the launcher will use (the partial totals are sized by it)
@@ -600,6 +602,14 @@ static int launch_bucket_j(const double *Y, i64 n, i64 row0, i64 rows, u64 *part
         if (lnb == 13 && u2 == 4) return launch_bucket_cfg<1024, 10, 13, 2, 4>(RB_ARGS);
     }
     switch (E) {
+        case 1: return launch_bucket_cfg<1024, 1, 13, J, 3>(RB_ARGS);
+        case 2: return launch_bucket_cfg<1024, 2, 13, J, 3>(RB_ARGS);
+        case 3: return launch_bucket_cfg<1024, 3, 13, J, 3>(RB_ARGS);
+        case 4: return launch_bucket_cfg<1024, 4, 13, J, 3>(RB_ARGS);
+        case 5: return launch_bucket_cfg<1024, 5, 14, J, 3>(RB_ARGS);
+        case 6: return launch_bucket_cfg<1024, 6, 14, J, 3>(RB_ARGS);
+        case 7: return launch_bucket_cfg<1024, 7, 14, J, 3>(RB_ARGS);
+        case 8: return launch_bucket_cfg<1024, 8, 14, J, 3>(RB_ARGS);
         case 9: return launch_bucket_cfg<1024, 9, 14, J, 3>(RB_ARGS);
         case 10: return launch_bucket_cfg<1024, 10, 14, J, 3>(RB_ARGS);
         case 11: return launch_bucket_cfg<1024, 11, 14, J, 3>(RB_ARGS);
@@ -610,7 +620,7 @@ static int launch_bucket_j(const double *Y, i64 n, i64 row0, i64 rows, u64 *part
         case 16: return launch_bucket_cfg<1024, 16, 13, J, 3>(RB_ARGS);
     }
 #undef RB_ARGS
-    return fail(SD_ERR_UNSUPPORTED, "bucket kernel covers 8192 < n <= 16384");
+    return fail(SD_ERR_UNSUPPORTED, "bucket kernel covers n <= 16384");
 }
 
 // rows [row0, row0 + rows): bucket kernel; returns the grid used (number of partial blocks) in *G_out

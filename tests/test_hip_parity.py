@@ -211,7 +211,7 @@ def test_mbd_high_J(eng, oracle):
 
 
 def test_rank_implementations_cross_check(eng, oracle, monkeypatch):
-    """The three rank implementations (packed keys + deferred rows, search for every row, first generation)
+    """The four rank implementations (bucket kernel, packed keys + deferred rows, search for every row, first generation)
     are independent pieces of code: they must agree with each other and with the oracle on ties, near-ties
     (values equal above the index field of the packed key) and specials."""
     rng = np.random.default_rng(99)
@@ -223,10 +223,62 @@ def test_rank_implementations_cross_check(eng, oracle, monkeypatch):
     cont[4, :7] = [np.inf, -np.inf, np.nan, 0.0, -0.0, 1.79e308, -1.79e308]
     for X in (base, near, big, tiny, cont):
         want = oracle.mbd_counts(X, None, 2)
-        for impl in ("3", "2", "1"):
+        for impl in ("4", "3", "2", "1"):
             monkeypatch.setenv("SD_RANK_IMPL", impl)
             assert (eng.mbd_counts(X, None, 2, algo="rank") == want).all(), impl
     monkeypatch.delenv("SD_RANK_IMPL")
+
+
+def _bucket_rows(rng, T, n):
+    """Rows that exercise every branch of the bucket kernel: plain, tied, NaN / +-inf, constant, crowded."""
+    X = rng.normal(size=(T, n)).cumsum(axis=0)
+    X[1] = np.round(X[1], 1)                         # ties inside buckets
+    X[2] = np.round(X[2], 0)                         # heavy ties: crowded buckets -> sorted behind the loop
+    X[3, ::9] = np.nan                               # NaNs stay out of the histogram
+    X[4, 5 % n] = np.inf                             # an infinity sets the row aside
+    X[4, 6 % n] = -np.inf
+    X[5, :] = 1.25                                   # all values equal
+    X[6, :] = np.nan                                 # nothing to rank
+    X[7, 1:] = np.nan                                # a single value
+    X[8] = np.exp(X[8])                              # skewed
+    X[9] = rng.standard_cauchy(n)                    # heavy tails: nearly everything in a few buckets
+    X[10, 0], X[10, n - 1] = 1.7e308, -1.7e308       # the range overflows
+    X[11] = X[11] * 1e-310                           # denormals
+    X[12, : n // 2] = X[12, n // 2: 2 * (n // 2)]    # pairs of equal values
+    X[13, : min(3, n)] = [0.0, -0.0, 5e-324][: min(3, n)]
+    return X
+
+
+@pytest.mark.parametrize("n", [2, 3, 64, 65, 1000, 1025, 3000, 8192, 8193, 10000, 12345, 16384])
+def test_bucket_kernel_rows(eng, oracle, monkeypatch, n):
+    """mbd_rank_bucket.hip (SD_RANK_IMPL=4, the default for n <= 16384) against the packed-sort path on every
+    curve and against the oracle on a sample of targets."""
+    rng = np.random.default_rng(n)
+    X = _bucket_rows(rng, 16, n)
+    for J in (2, 3):
+        if n - 1 < J:
+            continue
+        monkeypatch.setenv("SD_RANK_IMPL", "4")
+        got = eng.mbd_counts(X, None, J, algo="rank")
+        monkeypatch.setenv("SD_RANK_IMPL", "3")
+        assert (got == eng.mbd_counts(X, None, J, algo="rank")).all()
+        tg = np.unique(np.linspace(0, n - 1, 48).astype(np.int64))
+        assert (got[tg] == oracle.mbd_counts(X, tg, J)).all()
+    monkeypatch.delenv("SD_RANK_IMPL", raising=False)
+
+
+def test_bucket_kernel_many_rows_per_workgroup(eng, oracle):
+    """More rows than workgroups (several rows per workgroup, register accumulators across rows) with rows set aside
+    in between."""
+    rng = np.random.default_rng(8)
+    T, n = 1500, 700
+    X = rng.normal(size=(T, n)).cumsum(axis=0)
+    X[::7] = np.round(X[::7], 0)
+    X[5::11, 3] = np.inf
+    X[2::13, ::4] = np.nan
+    tg = np.arange(0, n, 9)
+    assert (eng.mbd_counts(X, tg, 2, algo="rank") == oracle.mbd_counts(X, tg, 2)).all()
+    assert (eng.mbd_counts(X, None, 2, algo="rank")[tg] == oracle.mbd_counts(X, tg, 2)).all()
 
 
 def test_above_below_vs_oracle(eng, oracle):

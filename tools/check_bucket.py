@@ -53,9 +53,13 @@ def case(name, X, J=2, reps=0, oracle_targets=64):
 def main():
     rng = np.random.default_rng(5)
     good = True
-    for n in (8193, 9000, 10000, 10240, 10241, 12000, 13313, 15000, 16384):
+    for n in (2, 3, 17, 64, 65, 300, 1023, 1024, 1025, 2049, 4096, 5000, 7777, 8192, 8193, 9000, 10000, 10240, 10241, 12000, 13313,
+              15000, 16384):
         X = rng.normal(size=(37, n)).cumsum(axis=0)
-        good &= case("walk", X)
+        good &= case("walk", X, oracle_targets=min(64, n))
+        if n < 9000:
+            Xt = np.round(X, 0); Xt[3, ::5] = np.nan; Xt[4, 1] = np.inf
+            good &= case("ints+nan", Xt, J=3 if n > 3 else 2, oracle_targets=min(64, n))
     X = rng.normal(size=(64, 10000)).cumsum(axis=0)
     good &= case("walk J=3", X, J=3)
     good &= case("ties (0.1)", np.round(X, 1))

@@ -13,6 +13,8 @@ X = np.random.default_rng(1234).normal(size=(T, n)).cumsum(axis=0)
 if os.environ.get("SD_TIES"):
     X = np.round(X, 1)
 Xd = engine.to_device_matrix(X)
+if os.environ.get("SD_RANK_IMPL"):
+    print("SD_RANK_IMPL =", os.environ["SD_RANK_IMPL"])
 for lvl in os.environ.get("SD_LEVELS", "0").split(","):
     if lvl != "0":
         os.environ["SD_RB_DBG"] = lvl
