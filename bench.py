@@ -140,7 +140,9 @@ def main():
     result_sum = int(out.sum().item())
     if rank == 0:
         used = "rank" if (args.algo == "rank" or (args.algo == "auto" and J <= 3)) else "pairwise"
-        kern = "mbd_pairwise_kernel" if used == "pairwise" else ("rank_packed_kernel" if n <= 16384 else "chunk_search_kernel")
+        # dominant kernel of the step: the bucket rank kernel (n <= 16384, J <= 3), the value-bucket sort of the large-n
+        # route, or the pairwise kernel
+        kern = "mbd_pairwise_kernel" if used == "pairwise" else ("rank_bucket_kernel" if n <= 16384 else "bucket_packed_kernel")
         bytes_alg = 8.0 * T * (n + n_loc) + 8.0 * n_loc * (J - 1)   # per GPU per call
         achieved = bytes_alg / (dev_ms * 1e-3)
         line = {

@@ -14,10 +14,11 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out = {}
 for gi, g in enumerate(groups):
     d = os.path.join(root, "gpurun_out", f"{tag}_g{gi}")
+    target = os.environ.get("PMC_CMD", "tools/time_rank.py 10000 1000 3").split()
     cmd = ["rocprofv3", "--pmc"] + g + ["--kernel-trace", "--output-format", "csv", "-d", d, "--",
-           sys.executable, os.path.join(root, "tools", "time_rank.py"), "10000", "1000", "3"]
+           sys.executable, os.path.join(root, target[0])] + target[1:]
     env = dict(os.environ, TMPDIR="/tmp")
-    r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=170)
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=170)
     print(f"group {gi} {g}: rc={r.returncode}", flush=True)
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         acc = {}
