@@ -33,6 +33,9 @@ namespace sd {
 
 constexpr u32 RB_AB_SPECIAL = 0xFFFFFFFFu;     // same encodings as mbd_rank_ab.hip
 constexpr u32 RB_ROW_DEFERRED = 0xFFFFFFFFu;
+#ifndef RB_INFLIGHT
+#define RB_INFLIGHT 2
+#endif
 constexpr int RB_PAD = 8;                      // NaN sentinels behind the bucket-ordered keys (never < or <= anything)
 
 // ---- wave64 cross-lane helpers on DPP (no LDS traffic, no ds_bpermute latency chain) ----
@@ -65,26 +68,44 @@ __device__ __forceinline__ double rb_readlane_f64(double v, int l) {
     return __longlong_as_double((long long)r);
 }
 
-template <int CTRL, int ROWMASK, bool MAX>
-__device__ __forceinline__ double rb_mm_step(double v) {
-    const u64 b = (u64)__double_as_longlong(v);
-    const u32 l = rb_dpp<CTRL, ROWMASK>((u32)b, (u32)b), h = rb_dpp<CTRL, ROWMASK>((u32)(b >> 32), (u32)(b >> 32));
-    const double o = __longlong_as_double((long long)(((u64)h << 32) | l));
-    return MAX ? (o > v ? o : v) : (o < v ? o : v);
+// v_min_f64 / v_max_f64 as single instructions (the builtins add a canonicalising v_max x,x,x per operand).  A quiet
+// NaN operand yields the other operand, so NaNs drop out of a reduction; a signalling NaN would poison it, which
+// only sends that row to the sort.
+template <bool MAX>
+__device__ __forceinline__ double rb_mm(double a, double b) {
+    double r;
+    if constexpr (MAX) asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    else asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
 }
 
-// min (or max) over each row of 16 lanes, valid in the row's last lane; ROWS = true carries on to lane 63
-template <bool MAX, bool ROWS>
-__device__ __forceinline__ double rb_minmax_last(double v) {
-    v = rb_mm_step<0x111, 0xF, MAX>(v);
-    v = rb_mm_step<0x112, 0xF, MAX>(v);
-    v = rb_mm_step<0x114, 0xF, MAX>(v);
-    v = rb_mm_step<0x118, 0xF, MAX>(v);
-    if constexpr (ROWS) {
-        v = rb_mm_step<0x142, 0xA, MAX>(v);
-        v = rb_mm_step<0x143, 0xC, MAX>(v);
-    }
+template <int CTRL>
+__device__ __forceinline__ double rb_dpp_f64(double v) {      // every lane has a source under row_ror: no old value
+    const u64 b = (u64)__double_as_longlong(v);
+    const u32 l = (u32)__builtin_amdgcn_mov_dpp((int)(u32)b, CTRL, 0xF, 0xF, false);
+    const u32 h = (u32)__builtin_amdgcn_mov_dpp((int)(u32)(b >> 32), CTRL, 0xF, 0xF, false);
+    return __longlong_as_double((long long)(((u64)h << 32) | l));
+}
+
+// min (or max) over each row of 16 lanes, in every lane of the row (rotations by 1, 2, 4, 8)
+template <bool MAX>
+__device__ __forceinline__ double rb_row_allreduce(double v) {
+    v = rb_mm<MAX>(v, rb_dpp_f64<0x121>(v));
+    v = rb_mm<MAX>(v, rb_dpp_f64<0x122>(v));
+    v = rb_mm<MAX>(v, rb_dpp_f64<0x124>(v));
+    v = rb_mm<MAX>(v, rb_dpp_f64<0x128>(v));
     return v;
+}
+
+// ... over the whole wave, wave-uniform (the four row results meet through SGPRs)
+template <bool MAX>
+__device__ __forceinline__ double rb_wave_allreduce(double v) {
+    v = rb_row_allreduce<MAX>(v);
+    double r = rb_readlane_f64(v, 0);
+    r = rb_mm<MAX>(r, rb_readlane_f64(v, 16));
+    r = rb_mm<MAX>(r, rb_readlane_f64(v, 32));
+    r = rb_mm<MAX>(r, rb_readlane_f64(v, 48));
+    return r;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -189,8 +210,10 @@ __global__ __launch_bounds__(NT) void rank_bucket_kernel(const double *__restric
     double *red = Sm;                                                 // [2][NW][2] min/max partials
     u32 *wtot = reinterpret_cast<u32 *>(red + 4 * NW);                // [NW]
     u32 *defer = wtot + NW;                                           // [DEFW] bitmap of the rows set aside
-    double *S = Sm + C::HDR / 8;                                      // keys in bucket order + sentinels + dummy
-    u32 *H = reinterpret_cast<u32 *>(S + C::keys_slots(n));           // NB packed u16 counters, then bases
+    // histogram before the keys: every LDS offset except the keys' end is a compile-time constant
+    u32 *H = reinterpret_cast<u32 *>(Sm + C::HDR / 8);                // NB packed u16 counters, then bases
+    double *S = reinterpret_cast<double *>(H + NB / 2 + 4);           // keys in bucket order + sentinels + dummy
+    double *IMG = reinterpret_cast<double *>(H);                      // sort image of the rows set aside (overlays both)
     const unsigned short *H16 = reinterpret_cast<const unsigned short *>(H);
     const int t0 = threadIdx.x;
     const double INF = __builtin_huge_val();
@@ -239,12 +262,11 @@ __global__ __launch_bounds__(NT) void rank_bucket_kernel(const double *__restric
         double mn = INF, mx = -INF;
 #pragma unroll
         for (int e = 0; e < E; ++e) {
-            const double x = k[e];
-            mn = x < mn ? x : mn;
-            mx = x > mx ? x : mx;
+            mn = rb_mm<false>(mn, k[e]);
+            mx = rb_mm<true>(mx, k[e]);
         }
-        mn = rb_minmax_last<false, true>(mn);
-        mx = rb_minmax_last<true, true>(mx);
+        mn = rb_wave_allreduce<false>(mn);
+        mx = rb_wave_allreduce<true>(mx);
         double *redp = red + par * 2 * NW;
         if (lane == 63) { redp[2 * wave] = mn; redp[2 * wave + 1] = mx; }
         par ^= 1;
@@ -252,8 +274,8 @@ __global__ __launch_bounds__(NT) void rank_bucket_kernel(const double *__restric
         double lo, hi;
         {
             const double2 p = reinterpret_cast<const double2 *>(redp)[lane & 15];
-            lo = rb_readlane_f64(rb_minmax_last<false, false>(p.x), 15);
-            hi = rb_readlane_f64(rb_minmax_last<true, false>(p.y), 15);
+            lo = rb_readlane_f64(rb_row_allreduce<false>(p.x), 0);
+            hi = rb_readlane_f64(rb_row_allreduce<true>(p.y), 0);
         }
         const double scale = (double)NB / (hi - lo);                  // range overflow -> 0 -> one crowded bucket
         // Every decision below is block-uniform.  The next row is loaded at ONE place (two load sites would
@@ -343,7 +365,7 @@ __global__ __launch_bounds__(NT) void rank_bucket_kernel(const double *__restric
             }
         }
         ++rowidx;
-        u32 bc[E];                                                    // base | count << 16 | slot << 24; count 0: NaN
+        u32 bc[E];                                                    // base | count << 16 | slot << 24; count 0: a NaN
         if (go) {
             __syncthreads();                                          // barrier 4
             // ---- (3) scatter into bucket order (branch-free; NaNs write the dummy slot) ----
@@ -355,7 +377,7 @@ __global__ __launch_bounds__(NT) void rank_bucket_kernel(const double *__restric
                 const u32 base = H16[b], end = H16[b + 1];
                 const bool isk = b < (u32)NB;
                 S[isk ? base + slot : (u32)DUMMY] = k[e];
-                bc[e] = isk ? (base | ((end - base) << 16) | (slot << 24)) : (u32)DUMMY;
+                bc[e] = isk ? (base | ((end - base) << 16) | (slot << 24)) : 0u;
             }
             if (nn && t < RB_PAD) S[nv + t] = QNAN;                   // sentinels behind a row shortened by NaNs
         }
@@ -448,28 +470,6 @@ __global__ __launch_bounds__(NT) void rank_bucket_kernel(const double *__restric
         }
     }
     t = t0;
-    // ---- the rows the bucket map could not spread (an infinity, all values equal, a crowded bucket): sort + search ----
-    if (ndefer) {                                                     // block-uniform, cold
-        __syncthreads();
-        rowidx = 0;
-        for (i64 r = blockIdx.x; r < rows; r += gridDim.x, ++rowidx) {
-            if (!((defer[rowidx >> 5] >> (rowidx & 31)) & 1u)) continue;
-            u32 ab[RB_SE], nnan_s;
-            rb_slow_row(Y + (row0 + r) * n, n, S, wtot, ab, &nnan_s);
-#pragma unroll
-            for (int e = 0; e < E; ++e) {
-                if (ab[e] != RB_AB_SPECIAL) {
-                    u64 a7[JMAX - 1] = {0, 0, 0, 0, 0, 0, 0};
-                    band_counts_add<J>(ab[e] >> 16, ab[e] & 0xFFFFu, nnan_s, (u64)(n - 1), a7);
-                    if constexpr (J == 2) acc[e][0] += 2 * a7[0];
-                    else {
-#pragma unroll
-                        for (int j = 0; j < J - 1; ++j) acc[e][j] += a7[j];
-                    }
-                }
-            }
-        }
-    }
     // ---- this workgroup's partial totals ----
     u64 *P = partial + (size_t)blockIdx.x * (J - 1) * n;
 #pragma unroll
@@ -478,6 +478,29 @@ __global__ __launch_bounds__(NT) void rank_bucket_kernel(const double *__restric
 #pragma unroll
             for (int j = 0; j < J - 1; ++j) P[(size_t)j * n + t + e * NT] = (J == 2) ? (acc[e][0] >> 1) : acc[e][j];
         }
+    // ---- the rows the bucket map could not spread (an infinity, all values equal, a crowded bucket): sort + search.
+    //      The main loop's accumulators are already in HBM and dead here, so this cold code shares no registers
+    //      with the hot loop; each thread adds its own curves' band counts to what it stored above. ----
+#ifndef RB_NO_COLD
+    if (ndefer) {                                                     // block-uniform
+        __syncthreads();
+        rowidx = 0;
+        for (i64 r = blockIdx.x; r < rows; r += gridDim.x, ++rowidx) {
+            if (!((defer[rowidx >> 5] >> (rowidx & 31)) & 1u)) continue;
+            u32 ab[RB_SE], nnan_s;
+            rb_slow_row(Y + (row0 + r) * n, n, IMG, wtot, ab, &nnan_s);
+#pragma unroll 1
+            for (int e = 0; e < RB_SE; ++e) {
+                if (ab[e] != RB_AB_SPECIAL) {                         // implies t + e * NT < n
+                    u64 a7[JMAX - 1] = {0, 0, 0, 0, 0, 0, 0};
+                    band_counts_add<J>(ab[e] >> 16, ab[e] & 0xFFFFu, nnan_s, (u64)(n - 1), a7);
+#pragma unroll
+                    for (int j = 0; j < J - 1; ++j) P[(size_t)j * n + t + e * NT] += a7[j];
+                }
+            }
+        }
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------
