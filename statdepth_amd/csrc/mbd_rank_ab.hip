@@ -393,9 +393,9 @@ static i64 ab_rows_per_batch(i64 T, i64 n) {
 // mbd_rank_bucket.hip
 bool mbd_rank_bucket_supported(i64 T, i64 n, int J);
 size_t mbd_rank_bucket_workspace_bytes(i64 rows, i64 n, int J);
-int launch_rank_bucket(const double *Y, i64 n, i64 row0, i64 rows, int J, u64 *partial, u32 *nnan,
-                       unsigned char *rowflag, int *G_out, hipStream_t s);
-int launch_rank_finalize(const u64 *partial, int G, const u32 *AB, const u32 *nnan, const unsigned char *rowflag,
+int launch_rank_bucket(const double *Y, i64 n, i64 row0, i64 rows, int J, u64 *partial, int *p32_out, int *G_out,
+                       hipStream_t s);
+int launch_rank_finalize(const u64 *partial, int G, int p32, const u32 *AB, const u32 *nnan, const unsigned char *rowflag,
                          i64 rows, i64 n, const i64 *targets, i64 tbegin, i64 m, int J, u64 *out, int first,
                          hipStream_t s);
 
@@ -473,8 +473,8 @@ int launch_mbd_rank(const double *Y, i64 T, i64 n, const i64 *targets, i64 tbegi
     for (i64 row0 = 0; row0 < T; row0 += rpb) {
         const i64 rows = T - row0 < rpb ? T - row0 : rpb;
         int rc;
-        int G = 0;
-        if (impl == 4 && (rc = launch_rank_bucket(Y, n, row0, rows, J, partial, nnan, rowflag, &G, s))) return rc;
+        int G = 0, p32 = 0;
+        if (impl == 4 && (rc = launch_rank_bucket(Y, n, row0, rows, J, partial, &p32, &G, s))) return rc;
         // E = 16 keys per thread throughout; smaller rows take smaller workgroups so that several rows are in
         // flight per CU (n = 4000: 4 workgroups of 256 threads per CU, 0.053 ms against 0.091 ms for 1024 x 4)
         if (impl == 4) rc = SD_OK;
@@ -487,7 +487,7 @@ int launch_mbd_rank(const double *Y, i64 T, i64 n, const i64 *targets, i64 tbegi
         dim3 grid((unsigned)((m + 63) / 64));
         const int first = row0 == 0;
         if (impl == 4) {   // the bucket kernel ranked every row itself: no pair image, no search launch
-            if ((rc = launch_rank_finalize(partial, G, nullptr, nullptr, nullptr, rows, n, targets, tbegin, m, J, out,
+            if ((rc = launch_rank_finalize(partial, G, p32, nullptr, nullptr, nullptr, rows, n, targets, tbegin, m, J, out,
                                            first, s)))
                 return rc;
             continue;

@@ -198,8 +198,7 @@ struct RBCfg {
 // prefix sum, 4 = after the scatter
 template <int NT, int E, int LNB, int J, int CAP, int U2, int DBG = 0>
 __global__ __launch_bounds__(NT) void rank_bucket_kernel(const double *__restrict__ Y, i64 n64, i64 row0, i64 rows,
-                                                         u64 *__restrict__ partial, u32 *__restrict__ nnan_out,
-                                                         unsigned char *__restrict__ rowflag) {
+                                                         u64 *__restrict__ partial, int p32) {
     using C = RBCfg<NT, E, LNB, U2>;
     constexpr int NB = C::NB, NW = C::NW, QW = C::QW;
     static_assert(2 * U2 - 1 <= RB_PAD, "the first member pass reads at most RB_PAD keys past the end");
@@ -470,13 +469,19 @@ __global__ __launch_bounds__(NT) void rank_bucket_kernel(const double *__restric
         }
     }
     t = t0;
-    // ---- this workgroup's partial totals ----
+    // ---- this workgroup's partial totals (u32 when the host found that they fit: J = 2, few rows per workgroup) ----
     u64 *P = partial + (size_t)blockIdx.x * (J - 1) * n;
+    u32 *P32 = reinterpret_cast<u32 *>(partial) + (size_t)blockIdx.x * n;
 #pragma unroll
     for (int e = 0; e < E; ++e)
         if (e < E - 1 || t + (E - 1) * NT < n) {
+            if constexpr (J == 2) {
+                if (p32) P32[t + e * NT] = (u32)(acc[e][0] >> 1);
+                else P[t + e * NT] = acc[e][0] >> 1;
+            } else {
 #pragma unroll
-            for (int j = 0; j < J - 1; ++j) P[(size_t)j * n + t + e * NT] = (J == 2) ? (acc[e][0] >> 1) : acc[e][j];
+                for (int j = 0; j < J - 1; ++j) P[(size_t)j * n + t + e * NT] = acc[e][j];
+            }
         }
     // ---- the rows the bucket map could not spread (an infinity, all values equal, a crowded bucket): sort + search.
     //      The main loop's accumulators are already in HBM and dead here, so this cold code shares no registers
@@ -494,8 +499,11 @@ __global__ __launch_bounds__(NT) void rank_bucket_kernel(const double *__restric
                 if (ab[e] != RB_AB_SPECIAL) {                         // implies t + e * NT < n
                     u64 a7[JMAX - 1] = {0, 0, 0, 0, 0, 0, 0};
                     band_counts_add<J>(ab[e] >> 16, ab[e] & 0xFFFFu, nnan_s, (u64)(n - 1), a7);
+                    if (J == 2 && p32) P32[t + e * NT] += (u32)a7[0];
+                    else {
 #pragma unroll
-                    for (int j = 0; j < J - 1; ++j) P[(size_t)j * n + t + e * NT] += a7[j];
+                        for (int j = 0; j < J - 1; ++j) P[(size_t)j * n + t + e * NT] += a7[j];
+                    }
                 }
             }
         }
@@ -509,7 +517,7 @@ __global__ __launch_bounds__(NT) void rank_bucket_kernel(const double *__restric
 // (the bucket kernel ranks every row itself).
 // ---------------------------------------------------------------------------------------------------
 template <int J>
-__global__ __launch_bounds__(1024) void rank_finalize_kernel(const u64 *__restrict__ partial, int G,
+__global__ __launch_bounds__(1024) void rank_finalize_kernel(const u64 *__restrict__ partial, int G, int p32,
                                                              const u32 *__restrict__ AB, const u32 *__restrict__ nnan,
                                                              const unsigned char *__restrict__ rowflag, i64 rows, i64 n,
                                                              const i64 *__restrict__ targets, i64 tbegin, i64 m,
@@ -528,11 +536,17 @@ __global__ __launch_bounds__(1024) void rank_finalize_kernel(const u64 *__restri
 #pragma unroll
     for (int j = 0; j < JMAX - 1; ++j) acc[j] = 0;
     if (q < m) {
-        const u64 *p = partial + i;
+        if (J == 2 && p32) {
+            const u32 *p = reinterpret_cast<const u32 *>(partial) + i;
 #pragma unroll 8
-        for (int g = y; g < G; g += 32) {
+            for (int g = y; g < G; g += 32) acc[0] += p[(size_t)g * n];
+        } else {
+            const u64 *p = partial + i;
+#pragma unroll 8
+            for (int g = y; g < G; g += 32) {
 #pragma unroll
-            for (int j = 0; j < J - 1; ++j) acc[j] += p[((size_t)g * (J - 1) + j) * n];
+                for (int j = 0; j < J - 1; ++j) acc[j] += p[((size_t)g * (J - 1) + j) * n];
+            }
         }
         if (any) {
             for (i64 r = y; r < rows; r += 32) {
@@ -585,8 +599,7 @@ size_t mbd_rank_bucket_workspace_bytes(i64 rows, i64 n, int J) {
 }
 
 template <int NT, int E, int LNB, int J, int U2>
-static int launch_bucket_cfg(const double *Y, i64 n, i64 row0, i64 rows, u64 *partial, u32 *nnan, unsigned char *rowflag,
-                             int G, hipStream_t s) {
+static int launch_bucket_cfg(const double *Y, i64 n, i64 row0, i64 rows, u64 *partial, int p32, int G, hipStream_t s) {
     using C = RBCfg<NT, E, LNB, U2>;
     auto kf = rank_bucket_kernel<NT, E, LNB, J, 40, U2>;
     if constexpr (E == 10 && J == 2 && LNB == 14 && U2 == 3) {
@@ -602,17 +615,16 @@ static int launch_bucket_cfg(const double *Y, i64 n, i64 row0, i64 rows, u64 *pa
     const size_t lds = C::lds_bytes((int)n);
     if (lds > 163840) return fail(SD_ERR_UNSUPPORTED, "bucket kernel: %zu bytes of LDS for n=%lld", lds, (long long)n);
     SD_HIP(hipFuncSetAttribute((const void *)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kf, dim3(G), dim3(NT), lds, s, Y, n, row0, rows, partial, nnan, rowflag);
+    hipLaunchKernelGGL(kf, dim3(G), dim3(NT), lds, s, Y, n, row0, rows, partial, p32);
     SD_HIP(hipGetLastError());
     return SD_OK;
 }
 
 template <int J>
-static int launch_bucket_j(const double *Y, i64 n, i64 row0, i64 rows, u64 *partial, u32 *nnan, unsigned char *rowflag,
-                           int G, hipStream_t s) {
+static int launch_bucket_j(const double *Y, i64 n, i64 row0, i64 rows, u64 *partial, int p32, int G, hipStream_t s) {
     // E = ceil(n / 1024); 16384 buckets while keys + histogram fit the 160 KiB of LDS, 8192 above;
     // first member pass: 3 x 16 bytes
-#define RB_ARGS Y, n, row0, rows, partial, nnan, rowflag, G, s
+#define RB_ARGS Y, n, row0, rows, partial, p32, G, s
     const int E = (int)((n + 1023) / 1024);
     if (E == 10 && J == 2) {                              // tuning experiments on the config-2 shape
         const char *eu = getenv("SD_RB_U2"), *el = getenv("SD_RB_LNB");
@@ -647,26 +659,30 @@ static int launch_bucket_j(const double *Y, i64 n, i64 row0, i64 rows, u64 *part
 }
 
 // rows [row0, row0 + rows): bucket kernel; returns the grid used (number of partial blocks) in *G_out
-int launch_rank_bucket(const double *Y, i64 n, i64 row0, i64 rows, int J, u64 *partial, u32 *nnan,
-                       unsigned char *rowflag, int *G_out, hipStream_t s) {
+int launch_rank_bucket(const double *Y, i64 n, i64 row0, i64 rows, int J, u64 *partial, int *p32_out, int *G_out,
+                       hipStream_t s) {
     const int cus = mbd_rank_bucket_max_grid();
     const int G = (int)(rows < cus ? rows : cus);
     *G_out = G;
     if (rows > (i64)G * 2048) return fail(SD_ERR_INVALID, "bucket kernel: more than 2048 rows per workgroup in one launch");
-    if (J == 2) return launch_bucket_j<2>(Y, n, row0, rows, partial, nnan, rowflag, G, s);
-    if (J == 3) return launch_bucket_j<3>(Y, n, row0, rows, partial, nnan, rowflag, G, s);
+    // J = 2: a workgroup's total is at most ceil(rows / G) * C(n-1, 2); below 2^32 the partials travel as u32
+    const u64 per_wg = (u64)((rows + G - 1) / G) * ((u64)(n - 1) * (u64)(n - 2) / 2);
+    const int p32 = (J == 2 && per_wg < ((u64)1 << 32)) ? 1 : 0;
+    *p32_out = p32;
+    if (J == 2) return launch_bucket_j<2>(Y, n, row0, rows, partial, p32, G, s);
+    if (J == 3) return launch_bucket_j<3>(Y, n, row0, rows, partial, p32, G, s);
     return fail(SD_ERR_UNSUPPORTED, "bucket kernel covers J in [2,3]");
 }
 
-int launch_rank_finalize(const u64 *partial, int G, const u32 *AB, const u32 *nnan, const unsigned char *rowflag,
+int launch_rank_finalize(const u64 *partial, int G, int p32, const u32 *AB, const u32 *nnan, const unsigned char *rowflag,
                          i64 rows, i64 n, const i64 *targets, i64 tbegin, i64 m, int J, u64 *out, int first,
                          hipStream_t s) {
     dim3 grid((unsigned)((m + 31) / 32));
     if (J == 2)
-        hipLaunchKernelGGL((rank_finalize_kernel<2>), grid, dim3(1024), 0, s, partial, G, AB, nnan, rowflag, rows, n, targets,
+        hipLaunchKernelGGL((rank_finalize_kernel<2>), grid, dim3(1024), 0, s, partial, G, p32, AB, nnan, rowflag, rows, n, targets,
                            tbegin, m, out, first);
     else
-        hipLaunchKernelGGL((rank_finalize_kernel<3>), grid, dim3(1024), 0, s, partial, G, AB, nnan, rowflag, rows, n, targets,
+        hipLaunchKernelGGL((rank_finalize_kernel<3>), grid, dim3(1024), 0, s, partial, G, p32, AB, nnan, rowflag, rows, n, targets,
                            tbegin, m, out, first);
     SD_HIP(hipGetLastError());
     return SD_OK;
