@@ -28,6 +28,7 @@
 
 #include "sd_common.h"
 #include "rank_sort.h"
+#include "rank_bucket.h"
 
 namespace sd {
 
@@ -366,6 +367,207 @@ __global__ __launch_bounds__(BK_NT) void bucket_packed_kernel(i64 n, int NB, con
     }
 }
 
+
+// A' (default): grid = 8 * NB * ceil(rows / 8) (see the mapping below).  Ranks inside one value bucket WITHOUT a sort, the method of mbd_rank_bucket.hip:
+// a monotone map of the bucket's keys onto NBF fine buckets (LDS histogram, the atomic's return value is the slot),
+// exclusive prefix sum, scatter into fine-bucket order, and every key counts the members of its own fine bucket that
+// are < / <= itself: B = (keys in earlier value buckets) + base + less, A = n_real - (... + base + le).  Ties are exact.
+// A value bucket whose keys are all equal is closed-form; one with a fine bucket above BR_CAP keys (heavy ties that
+// are not all equal, an infinity stretching the range) is flagged for bucket_search_kernel like before.
+constexpr int BR_NT = 512, BR_E = 16, BR_LNB = 12, BR_NBF = 1 << BR_LNB, BR_CAP = 40, BR_U2 = 3, BR_PAD = 8;
+constexpr int BR_NW = BR_NT / 64;
+static_assert(BR_NT * BR_E == BK_C, "one thread slot per key of a full value bucket");
+static_assert(BR_NBF / 2 / BR_NT == 4, "one 16-byte quad of histogram words per thread");
+constexpr size_t BR_HDR = 256;                                         // min/max partials [NW][2] doubles, wave totals [NW]
+constexpr size_t BR_LDS = BR_HDR + (size_t)(BR_NBF / 2 + 4) * 4 + (size_t)(BK_C + BR_PAD + 2 * BR_U2 + 4) * 8;
+
+__global__ __launch_bounds__(BR_NT) void bucket_rank_kernel(i64 n, i64 rows, int NB, const u32 *__restrict__ bcnt,
+                                                            const u32 *__restrict__ nnanrow,
+                                                            const u32 *__restrict__ ovf,
+                                                            const double *__restrict__ bval,
+                                                            const u32 *__restrict__ bidx, u32 *__restrict__ bflag,
+                                                            AB2 *__restrict__ ab) {
+    constexpr int E = BR_E, NT = BR_NT, NBF = BR_NBF, NW = BR_NW, U2 = BR_U2;
+    extern __shared__ double Sm[];
+    double *red = Sm;                                                 // [NW][2]
+    u32 *wtot = reinterpret_cast<u32 *>(red + 2 * NW);                // [NW], then the sum of the earlier buckets' counts
+    u32 *H = reinterpret_cast<u32 *>(Sm + BR_HDR / 8);                // NBF packed u16 counters, then bases
+    double *S = reinterpret_cast<double *>(H + NBF / 2 + 4);          // keys in fine-bucket order + NaN sentinels
+    const unsigned short *H16 = reinterpret_cast<const unsigned short *>(H);
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    // XCD-aware mapping (workgroups go to the 8 XCDs round-robin): all value buckets of a row run on ONE XCD, close in
+    // time, so the 8-byte pair writes they scatter over that row of the image meet in that XCD's L2 and leave it as
+    // whole lines.  grid.x = 8 * NB * ceil(rows / 8).
+    const int w = blockIdx.x;
+    const int b = (w >> 3) % NB;
+    const i64 rb = (i64)((w >> 3) / NB) * 8 + (w & 7);
+    if (rb >= rows) return;
+    if (ovf[rb]) return;
+    const u32 *rowcnt = bcnt + rb * NB;
+    const int cnt = (int)rowcnt[b];
+    if (cnt == 0) return;
+    const double INF = __builtin_huge_val();
+    const double QNAN = __builtin_nan("");
+    const size_t slot0 = ((size_t)rb * NB + b) * BK_C;
+
+    // keys of thread t: slots t, t + NT, ... (coalesced); slots beyond cnt read as NaN = "no key"
+    double k[E];
+    {
+        const double *rp = bval + slot0 + t;
+#pragma unroll
+        for (int e = 0; e < E; ++e) k[e] = (t + e * NT < cnt) ? rp[e * NT] : QNAN;
+    }
+    // keys in earlier value buckets of this row
+    u32 gsum = 0;
+    for (int q = t; q < b; q += NT) gsum += rowcnt[q];
+    gsum = rb_wave_incl_scan(gsum);
+    // LDS setup: empty histogram, sentinels behind the last key
+    reinterpret_cast<uint4 *>(H)[t] = make_uint4(0, 0, 0, 0);
+    if (t < 4) H[NBF / 2 + t] = 0;
+    if (t < BR_PAD + 2 * U2 + 4) S[cnt + t] = QNAN;
+    // range
+    double mn = INF, mx = -INF;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        if (e * NT >= cnt) break;                                     // block-uniform: key slots beyond the bucket's fill
+        mn = rb_mm<false>(mn, k[e]);
+        mx = rb_mm<true>(mx, k[e]);
+    }
+    mn = rb_wave_allreduce<false>(mn);
+    mx = rb_wave_allreduce<true>(mx);
+    if (lane == 63) { red[2 * wave] = mn; red[2 * wave + 1] = mx; wtot[wave] = gsum; }
+    __syncthreads();                                                  // barrier 1
+    double lo, hi;
+    u32 gbase;
+    {
+        const double2 p = reinterpret_cast<const double2 *>(red)[lane & (NW - 1)];
+        lo = rb_readlane_f64(rb_row_allreduce<false>(p.x), 0);        // rotations over 16 lanes see each of the 8 twice
+        hi = rb_readlane_f64(rb_row_allreduce<true>(p.y), 0);
+        const u32 g = (lane < NW) ? wtot[lane] : 0u;
+        gbase = rb_readlane(rb_row_incl_scan(g), 15);
+    }
+    const u32 nreal = (u32)n - nnanrow[rb];
+    AB2 *abrow = ab + rb * n;
+    const u32 *idp = bidx + slot0 + t;
+    if (!(hi > lo)) {
+        // every key of the bucket has the same value (or there is one key): all tied
+        if (hi == lo) {
+#pragma unroll
+            for (int e = 0; e < E; ++e)
+                if (t + e * NT < cnt) {
+                    AB2 v;
+                    v.B = gbase;
+                    v.A = nreal - gbase - (u32)cnt;
+                    abrow[idp[e * NT]] = v;
+                }
+        } else if (t == 0) bflag[rb * NB + b] = 1u;                   // a signalling NaN poisoned the range: sort it
+        return;
+    }
+    const double scale = (double)NBF / (hi - lo);                     // infinite range -> 0 -> one crowded fine bucket
+    if (!(scale < INF)) {                                             // block-uniform: denormal range
+        if (t == 0) bflag[rb * NB + b] = 1u;
+        return;
+    }
+    // ---- (1) fine bucket + slot ----
+    u32 bs[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        if (e * NT >= cnt) break;
+        const double x = k[e];
+        double u = (x - lo) * scale;
+        u = u > 0.0 ? u : 0.0;                                        // -inf (and NaN) -> 0
+        u = u < (double)(NBF - 1) ? u : (double)(NBF - 1);
+        u32 fb = (u32)u;
+        fb = (x == x) ? fb : (u32)(NBF + 2);                          // no key: dummy counter
+        const u32 sh = (fb & 1u) * 16u;
+        const u32 old = atomicAdd(&H[fb >> 1], 1u << sh);
+        bs[e] = fb | (((old >> sh) & 0xFFFFu) << 16);
+    }
+    __syncthreads();                                                  // barrier 2
+    // ---- (2) exclusive prefix sum; crowded fine bucket -> the search kernel ----
+    {
+        const uint4 hq = reinterpret_cast<const uint4 *>(H)[t];
+        constexpr u32 OVK = (u32)(0x7FFF - BR_CAP) * 0x10001u;
+        const u32 s4 = hq.x + hq.y + hq.z + hq.w;
+        const u32 ov = (hq.x + OVK) | (hq.y + OVK) | (hq.z + OVK) | (hq.w + OVK);
+        const u32 run = (s4 & 0xFFFFu) + (s4 >> 16);
+        const u32 incl = rb_wave_incl_scan(run);
+        const bool wover = __ballot((ov & 0x80008000u) != 0) != 0;
+        if (lane == 63) wtot[wave] = incl | (wover ? 0x80000000u : 0u);
+        __syncthreads();                                              // barrier 3
+        const u32 wt = (lane < NW) ? wtot[lane] : 0u;
+        const bool anyover = __ballot((wt >> 31) != 0) != 0;
+        if (anyover) {                                                // block-uniform
+            if (t == 0) bflag[rb * NB + b] = 1u;
+            return;
+        }
+        const u32 wscan = rb_row_incl_scan(wt & 0x7FFFFFFFu);
+        u32 base = (wave ? rb_readlane(wscan, wave - 1) : 0u) + incl - run;
+        uint4 o;
+        o.x = base | ((base + (hq.x & 0xFFFFu)) << 16);
+        base += (hq.x & 0xFFFFu) + (hq.x >> 16);
+        o.y = base | ((base + (hq.y & 0xFFFFu)) << 16);
+        base += (hq.y & 0xFFFFu) + (hq.y >> 16);
+        o.z = base | ((base + (hq.z & 0xFFFFu)) << 16);
+        base += (hq.z & 0xFFFFu) + (hq.z >> 16);
+        o.w = base | ((base + (hq.w & 0xFFFFu)) << 16);
+        base += (hq.w & 0xFFFFu) + (hq.w >> 16);
+        reinterpret_cast<uint4 *>(H)[t] = o;
+        if (t == NT - 1) H[NBF / 2] = base;                           // = cnt
+    }
+    __syncthreads();                                                  // barrier 4
+    // ---- (3) scatter into fine-bucket order ----
+    u32 bc[E];                                                        // base | count << 16; count 0: no key
+    const u32 dummy = (u32)(cnt + BR_PAD + 1) & ~1u;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        if (e * NT >= cnt) break;
+        const u32 fb = bs[e] & 0xFFFFu, slot = bs[e] >> 16;
+        const u32 base = H16[fb], end = H16[fb + 1];
+        const bool isk = fb < (u32)NBF;
+        S[isk ? base + slot : dummy] = k[e];
+        bc[e] = isk ? (base | ((end - base) << 16)) : 0u;
+    }
+    __syncthreads();                                                  // barrier 5
+    // ---- (4) rank inside the fine bucket (the keys are still in registers), write the pairs ----
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        if (e * NT >= cnt) break;
+        if ((e & 1) == 0) __builtin_amdgcn_sched_barrier(0);
+        const u32 base = bc[e] & 0xFFFFu, fc = bc[e] >> 16;
+        const u32 odd = base & 1u;
+        const double x = k[e];
+        const double2 *Sq = reinterpret_cast<const double2 *>(S + (base - odd));
+        u32 less = 0, le = 0;
+#pragma unroll
+        for (int u = 0; u < U2; ++u) {
+            const double2 y = Sq[u];
+            less += (y.x < x) ? 1u : 0u;
+            le += (y.x <= x) ? 1u : 0u;
+            less += (y.y < x) ? 1u : 0u;
+            le += (y.y <= x) ? 1u : 0u;
+        }
+        less -= odd;
+        le -= odd;
+        if (fc + odd > (u32)(2 * U2)) {                               // a fine bucket longer than the window
+            for (u32 kk = 2 * U2; kk < fc + odd; kk += 2) {
+                const double2 y = Sq[kk >> 1];
+                less += (y.x < x) ? 1u : 0u;
+                le += (y.x <= x) ? 1u : 0u;
+                less += (y.y < x) ? 1u : 0u;
+                le += (y.y <= x) ? 1u : 0u;
+            }
+        }
+        if (fc) {
+            AB2 v;
+            v.B = gbase + base + less;
+            v.A = nreal - (gbase + base + le);
+            abrow[idp[e * NT]] = v;
+        }
+    }
+}
+
 // B: grid = (NB, rows), flagged buckets only
 __global__ __launch_bounds__(BK_NT) void bucket_search_kernel(i64 n, int NB, const u32 *__restrict__ bcnt,
                                                               const u32 *__restrict__ nnanrow,
@@ -557,12 +759,16 @@ int launch_mbd_rank_big(const double *Y, i64 T, i64 n, const i64 *targets, i64 t
     auto k_cq = chunk_search_kernel;
     auto k_sp = bucket_splitters_kernel;
     auto k_bp = bucket_packed_kernel;
+    auto k_br = bucket_rank_kernel;
+    const char *envA = getenv("SD_BIG_SORT");                 // 1: packed-key sort per value bucket (predecessor, cross-check)
+    const bool rank_nosort = !(envA && atoi(envA) == 1);
     auto k_bs = bucket_search_kernel;
     const size_t lds_bk = BkCfg::LDS_BYTES + (size_t)BK_NT * 8;
     SD_HIP(hipFuncSetAttribute((const void *)k_cs, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BigCfg::LDS_BYTES));
     SD_HIP(hipFuncSetAttribute((const void *)k_cq, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BigCfg::LDS_BYTES));
     SD_HIP(hipFuncSetAttribute((const void *)k_sp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SsCfg::LDS_BYTES));
     SD_HIP(hipFuncSetAttribute((const void *)k_bp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bk));
+    SD_HIP(hipFuncSetAttribute((const void *)k_br, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BR_LDS));
     SD_HIP(hipFuncSetAttribute((const void *)k_bs, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BkCfg::LDS_BYTES));
 
     for (i64 row0 = 0; row0 < T; row0 += p.rpb) {
@@ -574,8 +780,13 @@ int launch_mbd_rank_big(const double *Y, i64 T, i64 n, const i64 *targets, i64 t
             hipLaunchKernelGGL(k_sp, dim3((unsigned)rows), dim3(256), SsCfg::LDS_BYTES, s, Y, n, row0, NB, spl);
             hipLaunchKernelGGL(bucket_partition_kernel, dim3((unsigned)((n + 16383) / 16384), (unsigned)rows), dim3(1024), 0,
                                s, Y, n, row0, NB, (const double *)spl, bcnt, nnanrow, ovf, bval, bidx, ab);
-            hipLaunchKernelGGL(k_bp, dim3((unsigned)NB, (unsigned)rows), dim3(BK_NT), lds_bk, s, n, NB, (const u32 *)bcnt,
-                               (const u32 *)nnanrow, (const u32 *)ovf, (const double *)bval, (const u32 *)bidx, bflag, ab);
+            if (rank_nosort)
+                hipLaunchKernelGGL(k_br, dim3((unsigned)(8 * NB * ((rows + 7) / 8))), dim3(BR_NT), BR_LDS, s, n, rows, NB,
+                                   (const u32 *)bcnt,
+                                   (const u32 *)nnanrow, (const u32 *)ovf, (const double *)bval, (const u32 *)bidx, bflag, ab);
+            else
+                hipLaunchKernelGGL(k_bp, dim3((unsigned)NB, (unsigned)rows), dim3(BK_NT), lds_bk, s, n, NB, (const u32 *)bcnt,
+                                   (const u32 *)nnanrow, (const u32 *)ovf, (const double *)bval, (const u32 *)bidx, bflag, ab);
             hipLaunchKernelGGL(k_bs, dim3((unsigned)NB, (unsigned)rows), dim3(BK_NT), BkCfg::LDS_BYTES, s, n, NB,
                                (const u32 *)bcnt, (const u32 *)nnanrow, (const u32 *)bflag, (const double *)bval,
                                (const u32 *)bidx, ab);
