@@ -6,6 +6,8 @@ _pointcloud.py:45), so rank r owns a block of curves, contributes it to an all-g
 its own curves against the gathered set.  Integer totals do not depend on the number of
 ranks.  The only other communication is the optional gather of the (tiny) results.
 """
+import os
+
 import numpy as np
 
 from . import engine
@@ -68,12 +70,21 @@ def _time_slices(T, world):
     return cnt, off
 
 
-def exchange_to_time_slices(X_loc, sizes, group=None):
+def _chunk_bounds(cnt, K):
+    """Row range [lo, hi) of sub-slice k inside a time slice of cnt rows, for k = 0..K-1 (as even as possible)."""
+    return [(cnt * k) // K for k in range(K + 1)]
+
+
+def exchange_to_time_slices(X_loc, sizes, group=None, chunk=0, chunks=1, async_op=False):
     """All-to-all that turns curve blocks into time slices.
 
     In: this rank's curves X_loc [T, n_loc] (time-major).  Out: X_rows [T_me, n] = ALL curves at this
     rank's timepoints (rank blocks side by side), plus the column offsets.  Each rank sends only
     (world-1)/world of its block and receives the same amount: 1/world of an all-gather's traffic.
+
+    chunks > 1: only sub-slice `chunk` of every rank's time slice travels (the caller pipelines the sub-slices
+    against the compute).  async_op=True returns (work, finish) instead: `finish()` waits for the exchange and
+    lays the rows out.
     """
     import torch
     dist = _dist()
@@ -81,23 +92,39 @@ def exchange_to_time_slices(X_loc, sizes, group=None):
     T, n_loc = X_loc.shape
     cnt, toff = _time_slices(T, world)
     offsets = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
-    t_me = cnt[rank]
-    send = X_loc.contiguous().view(-1)                       # rows of destination s are contiguous
-    in_split = [cnt[s] * n_loc for s in range(world)]
+    bounds = [_chunk_bounds(cnt[s], chunks) for s in range(world)]
+    rows_to = [bounds[s][chunk + 1] - bounds[s][chunk] for s in range(world)]     # rows this rank sends to s
+    t_me = rows_to[rank]
+    if chunks == 1:
+        send = X_loc.contiguous().view(-1)                   # rows of destination s are contiguous
+    else:                                                    # stage the sub-slices of all destinations back to back
+        send = torch.cat([X_loc[toff[s] + bounds[s][chunk]: toff[s] + bounds[s][chunk + 1]] for s in range(world)],
+                         dim=0).contiguous().view(-1)
+    in_split = [rows_to[s] * n_loc for s in range(world)]
     out_split = [t_me * int(sizes[r]) for r in range(world)]
     recv = torch.empty(int(sum(out_split)), dtype=X_loc.dtype, device=X_loc.device)
-    dist.all_to_all_single(recv, send, output_split_sizes=out_split, input_split_sizes=in_split, group=group)
+    work = dist.all_to_all_single(recv, send, output_split_sizes=out_split, input_split_sizes=in_split, group=group,
+                                  async_op=async_op)
     n = int(offsets[-1])
-    X_rows = torch.empty((t_me, n), dtype=X_loc.dtype, device=X_loc.device)
-    if min(sizes) == max(sizes):
-        X_rows.view(t_me, world, n_loc).copy_(recv.view(world, t_me, n_loc).permute(1, 0, 2))
-    else:
-        pos = 0
-        for r in range(world):
-            blk = recv[pos:pos + out_split[r]].view(t_me, int(sizes[r]))
-            X_rows[:, offsets[r]:offsets[r + 1]].copy_(blk)
-            pos += out_split[r]
-    return X_rows, offsets
+
+    def finish():
+        if work is not None:
+            work.wait()                                      # the current stream waits for the exchange
+        X_rows = torch.empty((t_me, n), dtype=X_loc.dtype, device=X_loc.device)
+        if min(sizes) == max(sizes):
+            X_rows.view(t_me, world, n_loc).copy_(recv.view(world, t_me, n_loc).permute(1, 0, 2))
+        else:
+            pos = 0
+            for r in range(world):
+                blk = recv[pos:pos + out_split[r]].view(t_me, int(sizes[r]))
+                X_rows[:, offsets[r]:offsets[r + 1]].copy_(blk)
+                pos += out_split[r]
+        _ = send                                             # the staging buffer lives as long as this closure
+        return X_rows
+
+    if async_op:
+        return work, finish
+    return finish(), offsets
 
 
 def _default_compute_all(X_rows, J, algo):
@@ -105,7 +132,7 @@ def _default_compute_all(X_rows, J, algo):
     return engine.mbd_counts(X_rows, None, J=J, algo=algo, return_tensor=True)
 
 
-def sharded_mbd_counts_time(X_loc, J=2, algo="auto", group=None, sizes=None, _compute_all=None):
+def sharded_mbd_counts_time(X_loc, J=2, algo="auto", group=None, sizes=None, _compute_all=None, chunks=None):
     """Time-sharded form of the same totals (the right decomposition for the rank kernels).
 
     The rank formulation sorts whole rows, so splitting the TARGETS would make every GPU sort every
@@ -123,13 +150,27 @@ def sharded_mbd_counts_time(X_loc, J=2, algo="auto", group=None, sizes=None, _co
         dist.all_gather_into_tensor(szt, torch.tensor([n_loc], dtype=torch.int64, device=X_loc.device), group=group)
         sizes = szt.cpu().tolist()
     sizes = [int(v) for v in sizes]
-    X_rows, offsets = exchange_to_time_slices(X_loc, sizes, group)
+    offsets = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
     n = int(offsets[-1])
-    if X_rows.shape[0] > 0:
-        part = (_compute_all or _default_compute_all)(X_rows, J, algo)
-        if not isinstance(part, torch.Tensor):
-            part = torch.as_tensor(np.asarray(part), device=X_loc.device)
-    else:
+    # The exchange is cut into K sub-slices of every rank's time slice; sub-slice k+1 travels (RCCL's stream) while
+    # the rows of sub-slice k are ranked (current stream).  K is the same on every rank: it depends on T and the
+    # world size only.
+    cnt, _ = _time_slices(T, world)
+    K = chunks if chunks is not None else int(os.environ.get("SD_DIST_CHUNKS", "2"))
+    K = max(1, min(K, min(cnt)))
+    compute = _compute_all or _default_compute_all
+    part = None
+    pending = exchange_to_time_slices(X_loc, sizes, group, 0, K, async_op=True)
+    for k in range(K):
+        nxt = exchange_to_time_slices(X_loc, sizes, group, k + 1, K, async_op=True) if k + 1 < K else None
+        X_rows = pending[1]()
+        pending = nxt
+        if X_rows.shape[0] > 0:
+            pk = compute(X_rows, J, algo)
+            if not isinstance(pk, torch.Tensor):
+                pk = torch.as_tensor(np.asarray(pk), device=X_loc.device)
+            part = pk if part is None else part + pk
+    if part is None:
         part = torch.zeros((n, J - 1), dtype=torch.int64, device=X_loc.device)
     part = part.contiguous()
     if min(sizes) == max(sizes) and dist.get_backend(group) == "nccl":

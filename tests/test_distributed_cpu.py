@@ -52,6 +52,11 @@ def _worker(rank, world, port, splits, J, q):
         loc_t = sharded_mbd_counts(X_loc, J=J, mode="time", **hooks)
         full_t = sharded_mbd_counts(X_loc, J=J, mode="auto", gather_result=True, **hooks)
         assert (loc_t == loc).all() and (full_t == full).all()
+        # the exchange pipelined in 1, 3 and (more sub-slices than rows per rank) 50 pieces: same integers
+        for k in ("1", "3", "50"):
+            os.environ["SD_DIST_CHUNKS"] = k
+            assert (sharded_mbd_counts(X_loc, J=J, mode="time", **hooks) == loc).all(), k
+        os.environ.pop("SD_DIST_CHUNKS")
         df = pd.DataFrame(X[:, lo:hi], columns=[f"c{i}" for i in range(lo, hi)])
         ser = sharded_functional_depth(df, J=J, relax=True, **hooks)
         q.put((rank, loc.numpy(), full.numpy(), ser))
