@@ -177,8 +177,26 @@ __global__ __launch_bounds__(NT) void rank_bucket_kernel(const double *__restric
 #pragma unroll
         for (int j = 0; j < NACC; ++j) acc[e][j] = 0;
 
-    if ((i64)blockIdx.x < rows) load_row(blockIdx.x);
+    // (0) range of a row = min / max of its keys (NaN never wins: pandas skipna, _containment.py:68-69), per wave into
+    // LDS.  It is computed for the NEXT row at the end of every iteration, where its VALU work fills the waits of
+    // the LDS-bound member passes, and once here for the first row.
+    auto row_range = [&](int parity) {
+        double mn = INF, mx = -INF;
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            mn = rb_mm<false>(mn, k[e]);
+            mx = rb_mm<true>(mx, k[e]);
+        }
+        mn = rb_wave_allreduce<false>(mn);
+        mx = rb_wave_allreduce<true>(mx);
+        double *rp = red + parity * 2 * NW;
+        if ((t & 63) == 63) { rp[2 * (t >> 6)] = mn; rp[2 * (t >> 6) + 1] = mx; }
+    };
     int par = 0;
+    if ((i64)blockIdx.x < rows) {
+        load_row(blockIdx.x);
+        row_range(0);
+    }
     for (i64 r = blockIdx.x; r < rows; r += gridDim.x) {
         const i64 rnext = r + gridDim.x;
         // Per-row opaque copy of the thread id: every address below derives from it, so the compiler recomputes
@@ -188,17 +206,7 @@ __global__ __launch_bounds__(NT) void rank_bucket_kernel(const double *__restric
         asm volatile("" : "+v"(t));
         const int lane = t & 63;
         const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-        // ---- (0) range of the row.  NaN never wins a comparison (pandas skipna, _containment.py:68-69) ----
-        double mn = INF, mx = -INF;
-#pragma unroll
-        for (int e = 0; e < E; ++e) {
-            mn = rb_mm<false>(mn, k[e]);
-            mx = rb_mm<true>(mx, k[e]);
-        }
-        mn = rb_wave_allreduce<false>(mn);
-        mx = rb_wave_allreduce<true>(mx);
         double *redp = red + par * 2 * NW;
-        if (lane == 63) { redp[2 * wave] = mn; redp[2 * wave + 1] = mx; }
         par ^= 1;
         __syncthreads();                                              // barrier 1 (histogram is zero, S is free)
         double lo, hi;
@@ -398,6 +406,7 @@ __global__ __launch_bounds__(NT) void rank_bucket_kernel(const double *__restric
                 }
             }
         }
+        if (rnext < rows) row_range(par);                             // the next row's keys have landed by now
     }
     t = t0;
     // ---- this workgroup's partial totals (u32 when the host found that they fit: J = 2, few rows per workgroup) ----
