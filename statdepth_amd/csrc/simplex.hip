@@ -15,6 +15,8 @@
 // enumeration (unrank once, then step), or one sampled subset each in the sampled
 // estimators.  Small dense fp64 systems per thread: VALU bound, no MFMA (systems are
 // (d+1)x(d+1) with d <= 8 and data-dependent pivoting).
+#include <stdlib.h>
+
 #include "sd_common.h"
 
 namespace sd {
@@ -217,6 +219,180 @@ __global__ __launch_bounds__(SX_THREADS) void simplex_kernel(
     if (threadIdx.x == 0 && tot) atomicAdd(&out[q], tot);
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Register-resident form of the same test for a compile-time dimension D and a NON-degenerate simplex
+// (D + 1 points of full rank -- every simplex of continuous data).  The (D+1) x (D+2) system lives in VGPRs:
+// every array index below is a compile-time constant, and the data-dependent row / column exchanges of the
+// pivoting are predicated exchanges with each candidate (v_cndmask) instead of indexed moves through scratch
+// memory.  The arithmetic is, operation for operation and in the same order, that of point_in_hull() /
+// solve_subset() above (pivot search order and strict ">" included), so the decision is the same bit for bit.
+// Returns 0 / 1 (outside / inside) or 2: the simplex is rank deficient, the caller falls back to point_in_hull().
+// ---------------------------------------------------------------------------------------------------
+template <int D>
+__device__ __forceinline__ int hull_full_rank(double (&R)[D + 1][D + 2], double scale, double tol) {
+    constexpr int K = D + 1;                  // points = rows = K; column K is the right-hand side
+    if (isinf(scale)) return 0;
+    const double rank_eps = 1e-10 * scale;
+    // ---- complete-pivoting elimination (point_in_hull) ----
+#pragma unroll
+    for (int rank = 0; rank < K; ++rank) {
+        int pr = -1, pc = -1;
+        double best = rank_eps;
+#pragma unroll
+        for (int r = rank; r < K; ++r)
+#pragma unroll
+            for (int c = rank; c < K; ++c) {
+                const double a = fabs(R[r][c]);
+                const bool gt = a > best;
+                best = gt ? a : best;
+                pr = gt ? r : pr;
+                pc = gt ? c : pc;
+            }
+        if (pr < 0) return 2;                 // rank deficient: Caratheodory enumeration in the generic code
+#pragma unroll
+        for (int rr = rank + 1; rr < K; ++rr) {           // exchange rows rank <-> pr
+            const bool sw = pr == rr;
+#pragma unroll
+            for (int k = 0; k <= K; ++k) {
+                const double a = R[rank][k], b = R[rr][k];
+                R[rank][k] = sw ? b : a;
+                R[rr][k] = sw ? a : b;
+            }
+        }
+#pragma unroll
+        for (int cc = rank + 1; cc < K; ++cc) {           // exchange columns rank <-> pc
+            const bool sw = pc == cc;
+#pragma unroll
+            for (int r = 0; r < K; ++r) {
+                const double a = R[r][rank], b = R[r][cc];
+                R[r][rank] = sw ? b : a;
+                R[r][cc] = sw ? a : b;
+            }
+        }
+#pragma unroll
+        for (int r = rank + 1; r < K; ++r) {
+            const double f = R[r][rank] / R[rank][rank];
+            const bool nz = f != 0.0;
+#pragma unroll
+            for (int c = rank; c <= K; ++c) {
+                const double v = R[r][c] - f * R[rank][c];
+                R[r][c] = nz ? v : R[r][c];
+            }
+        }
+    }
+    // ---- solve_subset with all K columns: partial pivoting on the (already triangular) system ----
+#pragma unroll
+    for (int c = 0; c < K; ++c) {
+        int p = c;
+        double best = fabs(R[c][c]);
+#pragma unroll
+        for (int r = c + 1; r < K; ++r) {
+            const double a = fabs(R[r][c]);
+            const bool gt = a > best;
+            best = gt ? a : best;
+            p = gt ? r : p;
+        }
+        if (best <= rank_eps) return 0;
+#pragma unroll
+        for (int rr = c + 1; rr < K; ++rr) {
+            const bool sw = p == rr;
+#pragma unroll
+            for (int k = 0; k <= K; ++k) {
+                const double a = R[c][k], b = R[rr][k];
+                R[c][k] = sw ? b : a;
+                R[rr][k] = sw ? a : b;
+            }
+        }
+#pragma unroll
+        for (int r = c + 1; r < K; ++r) {
+            const double f = R[r][c] / R[c][c];
+#pragma unroll
+            for (int k = c; k <= K; ++k) R[r][k] -= f * R[c][k];
+        }
+    }
+    double l[K];
+#pragma unroll
+    for (int c = K - 1; c >= 0; --c) {
+        double sacc = R[c][K];
+#pragma unroll
+        for (int k = c + 1; k < K; ++k) sacc -= R[c][k] * l[k];
+        l[c] = sacc / R[c][c];
+    }
+    bool in = true;
+#pragma unroll
+    for (int c = 0; c < K; ++c) in = in && (l[c] >= -tol);
+    return in ? 1 : 0;
+}
+
+// grid = (chunks, m), the work decomposition of simplex_kernel; D = d known at compile time.
+template <int D>
+__global__ __launch_bounds__(SX_THREADS) void simplex_kernel_fast(
+    const double *__restrict__ P, i64 n, i64 T, const i64 *__restrict__ targets, int relax, double tol,
+    u64 total, u64 per_thread, i64 samples, u64 seed, i64 q0, u64 *__restrict__ out) {
+    __shared__ u64 scratch[SX_THREADS / 64];
+    constexpr int K = D + 1;
+    const i64 q = q0 + blockIdx.y;
+    const i64 tg = targets ? targets[q] : q;
+    const i64 no = n - 1;
+    const u64 tid = (u64)blockIdx.x * SX_THREADS + threadIdx.x;
+    const u64 first = tid * per_thread;
+    u64 acc = 0;
+    if (first < total) {
+        const u64 last = first + per_thread < total ? first + per_thread : total;
+        i64 idx[SMAX];
+        if (samples < 0) unrank_comb(first, K, no, idx);
+        const i64 TT = T > 0 ? T : 1;
+        for (u64 r = first; r < last; ++r) {
+            if (samples >= 0) sample_subset(seed, (u64)tg, r, K, no, idx);
+            u64 cnt = 0;
+            for (i64 t = 0; t < TT; ++t) {
+                double R[K][K + 1];
+                double scale = 1.0;
+                bool anynan = false;
+                const double *xx = P + (tg * TT + t) * D;
+#pragma unroll
+                for (int c = 0; c < K; ++c) {
+                    const i64 src = idx[c] < tg ? idx[c] : idx[c] + 1;     // skip the target itself
+                    const double *pp = P + (src * TT + t) * D;
+#pragma unroll
+                    for (int e = 0; e < D; ++e) {
+                        const double v = pp[e];
+                        anynan |= v != v;
+                        R[e][c] = v;
+                        scale = fabs(v) > scale ? fabs(v) : scale;
+                    }
+                    R[D][c] = 1.0;
+                }
+#pragma unroll
+                for (int e = 0; e < D; ++e) {
+                    const double v = xx[e];
+                    anynan |= v != v;
+                    R[e][K] = v;
+                    scale = fabs(v) > scale ? fabs(v) : scale;
+                }
+                R[D][K] = 1.0;
+                int res = anynan ? 0 : hull_full_rank<D>(R, scale, tol);
+                if (res == 2) {                                         // degenerate simplex: generic code, from the data
+                    double pts[SMAX * 8], x[8];
+                    for (int c = 0; c < K; ++c) {
+                        const i64 src = idx[c] < tg ? idx[c] : idx[c] + 1;
+                        const double *pp = P + (src * TT + t) * D;
+                        for (int e = 0; e < D; ++e) pts[c * D + e] = pp[e];
+                    }
+                    for (int e = 0; e < D; ++e) x[e] = xx[e];
+                    res = point_in_hull(pts, K, D, x, tol) ? 1 : 0;
+                }
+                cnt += (u64)res;
+            }
+            acc += (T > 0 && !relax) ? (cnt / (u64)TT) : cnt;
+            if (samples < 0 && r + 1 < last) next_comb(idx, K, no);
+        }
+    }
+    u64 tot = block_sum_u64(acc, scratch);
+    if (threadIdx.x == 0 && tot) atomicAdd(&out[q], tot);
+}
+
+
 static int launch_simplex_common(const double *P, i64 n, i64 T, int d, const i64 *targets, i64 m, int relax,
                                  double tol, i64 samples, u64 seed, u64 *out, hipStream_t s) {
     SD_HIP(hipMemsetAsync(out, 0, sizeof(u64) * m, s));
@@ -235,8 +411,21 @@ static int launch_simplex_common(const double *P, i64 n, i64 T, int d, const i64
     for (i64 q0 = 0; q0 < m; q0 += 65535) {   // grid.y limit: fold large m into several launches
         i64 mm = m - q0 < 65535 ? m - q0 : 65535;
         dim3 grid((unsigned)blocks, (unsigned)mm);
-        hipLaunchKernelGGL(simplex_kernel, grid, dim3(SX_THREADS), 0, s, P, n, T, d, targets, relax, tol, total,
-                           per_thread, samples, seed, q0, out);
+#define SX_FAST(D_) case D_: hipLaunchKernelGGL((simplex_kernel_fast<D_>), grid, dim3(SX_THREADS), 0, s, P, n, T, targets, \
+                                                 relax, tol, total, per_thread, samples, seed, q0, out); break;
+        const char *eg = getenv("SD_SIMPLEX_GENERIC");       // 1: the generic (scratch-memory) kernel, cross-check
+        if (eg && atoi(eg) == 1) {
+            hipLaunchKernelGGL(simplex_kernel, grid, dim3(SX_THREADS), 0, s, P, n, T, d, targets, relax, tol, total,
+                               per_thread, samples, seed, q0, out);
+        } else {
+            switch (d) {
+                SX_FAST(1) SX_FAST(2) SX_FAST(3) SX_FAST(4) SX_FAST(5) SX_FAST(6) SX_FAST(7) SX_FAST(8)
+                default:
+                    hipLaunchKernelGGL(simplex_kernel, grid, dim3(SX_THREADS), 0, s, P, n, T, d, targets, relax, tol,
+                                       total, per_thread, samples, seed, q0, out);
+            }
+        }
+#undef SX_FAST
     }
     SD_HIP(hipGetLastError());
     return SD_OK;
