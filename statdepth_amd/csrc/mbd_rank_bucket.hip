@@ -538,17 +538,20 @@ size_t mbd_rank_bucket_workspace_bytes(i64 rows, i64 n, int J) {
     return align_up((size_t)mbd_rank_bucket_max_grid() * (J - 1) * n * 8, 256) + align_up((size_t)rows, 256) + 512;
 }
 
+#ifndef RB_CAP
+#define RB_CAP 80
+#endif
 template <int NT, int E, int LNB, int J, int U2>
 static int launch_bucket_cfg(const double *Y, i64 n, i64 row0, i64 rows, u64 *partial, int p32, int G, hipStream_t s) {
     using C = RBCfg<NT, E, LNB, U2>;
-    auto kf = rank_bucket_kernel<NT, E, LNB, J, 40, U2>;
+    auto kf = rank_bucket_kernel<NT, E, LNB, J, RB_CAP, U2>;
     if constexpr (E == 10 && J == 2 && LNB == 14 && U2 == 3) {
         if (const char *d = getenv("SD_RB_DBG")) {        // timing experiments: truncated kernels
             switch (atoi(d)) {
-                case 1: kf = rank_bucket_kernel<NT, E, LNB, J, 40, U2, 1>; break;
-                case 2: kf = rank_bucket_kernel<NT, E, LNB, J, 40, U2, 2>; break;
-                case 3: kf = rank_bucket_kernel<NT, E, LNB, J, 40, U2, 3>; break;
-                case 4: kf = rank_bucket_kernel<NT, E, LNB, J, 40, U2, 4>; break;
+                case 1: kf = rank_bucket_kernel<NT, E, LNB, J, RB_CAP, U2, 1>; break;
+                case 2: kf = rank_bucket_kernel<NT, E, LNB, J, RB_CAP, U2, 2>; break;
+                case 3: kf = rank_bucket_kernel<NT, E, LNB, J, RB_CAP, U2, 3>; break;
+                case 4: kf = rank_bucket_kernel<NT, E, LNB, J, RB_CAP, U2, 4>; break;
             }
         }
     }
