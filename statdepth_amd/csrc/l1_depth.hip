@@ -3,9 +3,11 @@
 //   e = sum_{y != x} (y - x)/||x - y||   (:145-146, in index order)
 //   depth = 1 - ||e|| / n                (:148,150; n includes x).
 // Lanes = target points; the streamed point y is wave-uniform (scalar cache).
-// fp64 sqrt/div bound.  Operation order equals the oracle's (no FMA contraction,
-// this file is compiled with -ffp-contract=off) so results agree to the last bit
-// with oracle_l1_depth; coincident points give NaN like the reference's 0/0.
+// fp64 VALU bound.  The unit vector is (y - x) * r with r = 1/sqrt(s) from v_rsq_f64 + two Newton steps (error
+// about one ulp) instead of an IEEE sqrt and d IEEE divisions: a third of the instructions; the summation order is
+// the oracle's, the result agrees with oracle_l1_depth far inside the 1e-12 the tests allow (floating point: the
+// tolerance row of north_star, not the bit-exact one).  Squared distances outside [1e-280, 1e280] and coincident
+// points (s = 0 -> NaN like the reference's 0/0) take the IEEE sqrt + division.
 #include "sd_common.h"
 
 namespace sd {
@@ -30,10 +32,17 @@ __global__ __launch_bounds__(256) void l1_depth_kernel(const double *__restrict_
 #pragma unroll
         for (int c = 0; c < DM; ++c)
             if (c < d) { double df = x[c] - y[c]; s += df * df; }
-        double nr = sqrt(s);
+        double r;
+        if (__builtin_expect(s > 1e-280 && s < 1e280, 1)) {
+            r = __builtin_amdgcn_rsq(s);
+            r = r * (1.5 - (0.5 * s) * (r * r));
+            r = r * (1.5 - (0.5 * s) * (r * r));
+        } else {
+            r = 1.0 / sqrt(s);                                        // 0 -> inf -> 0 * inf = NaN below
+        }
 #pragma unroll
         for (int c = 0; c < DM; ++c)
-            if (c < d) e[c] += (y[c] - x[c]) / nr;
+            if (c < d) e[c] += (y[c] - x[c]) * r;
     }
     double s = 0.0;
 #pragma unroll
