@@ -13,6 +13,8 @@
 // Phase 1 builds the masks (coalesced row reads, target value wave-uniform);
 // phase 2 counts subsets: lanes = curve a (masks in VGPRs), partner b wave-uniform
 // through the scalar cache.  Integer work, VALU-bound (64-bit AND/OR), no MFMA.
+#include <stdlib.h>
+
 #include "sd_common.h"
 
 namespace sd {
@@ -136,6 +138,139 @@ __global__ __launch_bounds__(ST_THREADS) void strict_pairs_kernel(
     if (threadIdx.x == 0 && tot) atomicAdd(&out[q * jcols], tot);
 }
 
+// ---------------------------------------------------------------------------------------------------
+// J = 2, second generation (T <= 1024): 32-bit mask words in a word-major image m32[b][k][i] (k < W32: UN word k,
+// k >= W32: DN word k - W32; the n curves of one word are contiguous, so every access below is coalesced).
+//  strict_masks2_kernel  thread = curve, block = 256 curves x one word (32 timepoints) x a group of 32 targets: the
+//      curve's 32 values stay in VGPRs across the targets (the first generation re-read the matrix once per target:
+//      m n T loads from L2), the target's values are wave-uniform scalar loads.
+//  strict_pairs2_kernel  the lane's own masks live in VGPRs (32 + 32 words); the partners come in sub-chunks of 64
+//      whose masks are staged in LDS (16 KiB).  Pass 1 tests the first four words (128 timepoints) of every partner
+//      branch-free (wave-uniform LDS addresses: broadcasts) and records the survivors as one bit per partner; pass 2
+//      walks the remaining words only for the survivors (most pairs conflict early).  The first generation read the
+//      partner's words through the scalar cache inside a loop with an early exit, which serialised on the
+//      scalar-load latency (~1500 cycles per partner and wave).
+// ---------------------------------------------------------------------------------------------------
+constexpr int ST_W32 = 32;                  // mask words per kind kept in registers (T <= 1024)
+constexpr int ST_TG = 32;                   // targets per block of the mask kernel
+constexpr int ST_SUB = 64;
+
+// grid = (ceil(n / 256), W32, ceil(nb / ST_TG))
+__global__ __launch_bounds__(ST_THREADS) void strict_masks2_kernel(
+    const double *__restrict__ Y, i64 T, i64 n, const i64 *__restrict__ targets, i64 q0, i64 nb,
+    u32 *__restrict__ m32, u32 *__restrict__ xnan) {
+    const i64 i = (i64)blockIdx.x * ST_THREADS + threadIdx.x;
+    const int k = blockIdx.y;
+    const int W32 = (int)((T + 31) / 32);
+    const i64 t0 = (i64)k * 32;
+    const int tl = (int)(T - t0 < 32 ? T - t0 : 32);
+    double x[32];
+    u32 nanbits = 0;
+#pragma unroll
+    for (int t = 0; t < 32; ++t) {
+        x[t] = (i < n && t < tl) ? Y[(t0 + t) * n + i] : 0.0;
+        nanbits |= (x[t] != x[t]) ? (1u << t) : 0u;
+    }
+    const i64 bend = ((i64)blockIdx.z + 1) * ST_TG < nb ? ((i64)blockIdx.z + 1) * ST_TG : nb;
+    for (i64 b = (i64)blockIdx.z * ST_TG; b < bend; ++b) {
+        const i64 tg = targets ? targets[q0 + b] : q0 + b;
+        u32 un = nanbits, dn = nanbits;
+        bool tnan = false;
+#pragma unroll
+        for (int t = 0; t < 32; ++t) {
+            if (t < tl) {                                   // block-uniform
+                const double xq = Y[(t0 + t) * n + tg];     // wave-uniform: scalar load
+                tnan |= xq != xq;
+                un |= (x[t] > xq) ? (1u << t) : 0u;
+                dn |= (x[t] < xq) ? (1u << t) : 0u;
+            }
+        }
+        if (i < n) {
+            m32[((size_t)b * 2 * W32 + k) * n + i] = un;
+            m32[((size_t)b * 2 * W32 + W32 + k) * n + i] = dn;
+        }
+        if (tnan && blockIdx.x == 0 && threadIdx.x == 0) xnan[b] = 1;
+    }
+}
+
+// grid = (a tiles, b chunks, batch)
+__global__ __launch_bounds__(ST_THREADS) void strict_pairs2_kernel(
+    const u32 *__restrict__ m32, i64 T, i64 n, const i64 *__restrict__ targets, i64 q0,
+    const u32 *__restrict__ xnan, u64 *__restrict__ out, int jcols) {
+    __shared__ u64 scratch[ST_THREADS / 64];
+    __shared__ __attribute__((aligned(16))) u32 cm[ST_SUB][2 * ST_W32 + 4];   // partner j: UN words 0..31, DN words 0..31 (zero
+                                                                                // beyond W32); rows padded by 16 bytes: the survivors'
+                                                                                // per-lane rows fall on different banks
+    const i64 b = blockIdx.z;
+    const i64 q = q0 + b;
+    if (xnan[b]) return;                       // NaN in the target: nothing is contained
+    const i64 tg = targets ? targets[q] : q;
+    const i64 a = (i64)blockIdx.x * ST_THREADS + threadIdx.x;
+    const i64 b0 = (i64)blockIdx.y * ST_BCHUNK;
+    const i64 b1 = b0 + ST_BCHUNK < n ? b0 + ST_BCHUNK : n;
+    const i64 amin = (i64)blockIdx.x * ST_THREADS;
+    if (b1 - 1 <= amin) return;                // whole chunk at or below the tile: no a < b pair
+    const int W32 = (int)((T + 31) / 32);
+    const u32 *mb = m32 + (size_t)b * 2 * W32 * n;
+    const bool alive = a < n && a != tg;
+    u32 un[ST_W32], dn[ST_W32];
+#pragma unroll
+    for (int w = 0; w < ST_W32; ++w) {
+        un[w] = (alive && w < W32) ? mb[(size_t)w * n + a] : 0u;
+        dn[w] = (alive && w < W32) ? mb[(size_t)(W32 + w) * n + a] : 0u;
+    }
+    u64 good = 0;
+    for (i64 s0 = b0; s0 < b1; s0 += ST_SUB) {
+        const int len = (int)(b1 - s0 < ST_SUB ? b1 - s0 : ST_SUB);
+        __syncthreads();                                        // the previous sub-chunk has been read
+        for (int e = threadIdx.x; e < ST_SUB * 2 * ST_W32; e += ST_THREADS) {
+            const int w2 = e / ST_SUB, j = e % ST_SUB;          // consecutive threads: consecutive partners of one word
+            const int w = w2 % ST_W32;
+            u32 v = 0;
+            if (j < len && w < W32) v = mb[(size_t)(w2 < ST_W32 ? w : W32 + w) * n + s0 + j];
+            cm[j][w2] = v;
+        }
+        __syncthreads();
+        // ---- pass 1: first four words of every partner; survivors as bits ----
+        u64 surv = 0;
+#pragma unroll 8
+        for (int j = 0; j < ST_SUB; ++j) {
+            const uint4 cu = *reinterpret_cast<const uint4 *>(&cm[j][0]);
+            const uint4 cd = *reinterpret_cast<const uint4 *>(&cm[j][ST_W32]);
+            const u32 bad = (un[0] & cu.x) | (un[1] & cu.y) | (un[2] & cu.z) | (un[3] & cu.w) | (dn[0] & cd.x) |
+                            (dn[1] & cd.y) | (dn[2] & cd.z) | (dn[3] & cd.w);
+            surv |= (u64)(bad == 0) << j;
+        }
+        // real partners only (a curve that ties with the target everywhere has empty masks and conflicts with nothing,
+        // not even with the padding or the target's own slot): block-uniform mask; then c > a only
+        u64 real = len == ST_SUB ? ~0ull : (((u64)1 << len) - 1);
+        if (tg >= s0 && tg < s0 + len) real &= ~((u64)1 << (int)(tg - s0));
+        surv = alive ? (surv & real) : 0;
+        const i64 jf = a + 1 - s0;
+        surv = (jf <= 0) ? surv : (jf >= 64 ? 0 : (surv >> (int)jf) << (int)jf);
+        if (W32 <= 4) {
+            good += (u64)__popcll(surv);
+        } else {
+            // ---- pass 2: the survivors' remaining words ----
+            while (surv) {
+                const int j = __ffsll((long long)surv) - 1;
+                surv &= surv - 1;
+                u32 bad = 0;
+#pragma unroll
+                for (int w = 4; w < ST_W32; w += 4) {                   // 16-byte LDS reads (per-lane partner j)
+                    const uint4 cu = *reinterpret_cast<const uint4 *>(&cm[j][w]);
+                    const uint4 cd = *reinterpret_cast<const uint4 *>(&cm[j][ST_W32 + w]);
+                    bad |= (un[w] & cu.x) | (un[w + 1] & cu.y) | (un[w + 2] & cu.z) | (un[w + 3] & cu.w) | (dn[w] & cd.x) |
+                           (dn[w + 1] & cd.y) | (dn[w + 2] & cd.z) | (dn[w + 3] & cd.w);
+                }
+                good += (bad == 0);
+            }
+        }
+    }
+    u64 tot = block_sum(good, scratch);
+    if (threadIdx.x == 0 && tot) atomicAdd(&out[q * jcols], tot);
+}
+
 // J = 3 / 4: one thread per (J-1)-prefix, loop over the last member.
 template <int J>
 __global__ __launch_bounds__(ST_THREADS) void strict_subsets_kernel(
@@ -198,8 +333,19 @@ int launch_bd_strict(const double *Y, i64 T, i64 n, const i64 *targets, i64 m, i
         i64 nb = m - q0 < B ? m - q0 : B;
         SD_HIP(hipMemsetAsync(xnan, 0, (size_t)nb * 4, s));
         dim3 g1((unsigned)((n + ST_THREADS - 1) / ST_THREADS), (unsigned)nb);
-        hipLaunchKernelGGL(strict_masks_kernel, g1, dim3(ST_THREADS), 0, s, Y, T, n, targets, q0, masks, xnan);
         dim3 g2((unsigned)((n + ST_THREADS - 1) / ST_THREADS), (unsigned)((n + ST_BCHUNK - 1) / ST_BCHUNK), (unsigned)nb);
+        const char *e1 = getenv("SD_STRICT_V1");             // 1: first-generation kernels (cross-check)
+        const i64 W32 = (T + 31) / 32;
+        if (!(e1 && atoi(e1) == 1) && J == 2 && W32 <= ST_W32) {
+            // second generation: 32-bit words, word-major image (fits the same workspace: 2 W32 n u32 <= 2 W n u64)
+            dim3 g1b((unsigned)((n + ST_THREADS - 1) / ST_THREADS), (unsigned)W32, (unsigned)((nb + ST_TG - 1) / ST_TG));
+            hipLaunchKernelGGL(strict_masks2_kernel, g1b, dim3(ST_THREADS), 0, s, Y, T, n, targets, q0, nb, (u32 *)masks, xnan);
+            hipLaunchKernelGGL(strict_pairs2_kernel, g2, dim3(ST_THREADS), 0, s, (const u32 *)masks, T, n, targets, q0, xnan,
+                               out, jcols);
+            SD_HIP(hipGetLastError());
+            continue;
+        }
+        hipLaunchKernelGGL(strict_masks_kernel, g1, dim3(ST_THREADS), 0, s, Y, T, n, targets, q0, masks, xnan);
         if (W <= ST_WREG)
             hipLaunchKernelGGL((strict_pairs_kernel<true>), g2, dim3(ST_THREADS), 0, s, masks, T, n, targets, q0, xnan, out, jcols);
         else
