@@ -142,7 +142,7 @@ def main():
         used = "rank" if (args.algo == "rank" or (args.algo == "auto" and J <= 3)) else "pairwise"
         # dominant kernel of the step: the bucket rank kernel (n <= 16384, J <= 3), the value-bucket sort of the large-n
         # route, or the pairwise kernel
-        kern = "mbd_pairwise_kernel" if used == "pairwise" else ("rank_bucket_kernel" if n <= 16384 else "bucket_packed_kernel")
+        kern = "mbd_pairwise_kernel" if used == "pairwise" else ("rank_bucket_kernel" if n <= 16384 else "bucket_rank_kernel")
         bytes_alg = 8.0 * T * (n + n_loc) + 8.0 * n_loc * (J - 1)   # per GPU per call
         achieved = bytes_alg / (dev_ms * 1e-3)
         line = {
