@@ -287,7 +287,8 @@ def test_above_below_vs_oracle(eng, oracle):
     assert (eng.above_below(X) == oracle.above_below(X)).all()
 
 
-@pytest.mark.parametrize("shape", [(5, 6), (64, 40), (65, 130), (200, 77), (1030, 45)])
+@pytest.mark.parametrize("shape", [(5, 6), (32, 70), (33, 600), (64, 40), (65, 130), (128, 300), (129, 700), (200, 77),
+                                   (1024, 300), (1030, 45)])
 def test_strict_vs_oracle(eng, oracle, shape):
     rng = np.random.default_rng(shape[0] * 1000 + shape[1])
     T, n = shape
