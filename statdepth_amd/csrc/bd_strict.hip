@@ -198,6 +198,7 @@ __global__ __launch_bounds__(ST_THREADS) void strict_pairs2_kernel(
     const u32 *__restrict__ m32, i64 T, i64 n, const i64 *__restrict__ targets, i64 q0,
     const u32 *__restrict__ xnan, u64 *__restrict__ out, int jcols) {
     __shared__ u64 scratch[ST_THREADS / 64];
+    __shared__ u32 orparts[ST_THREADS / 64][2][ST_SUB];   // per wave: OR of its quarter of partner j's UN / DN words
     __shared__ __attribute__((aligned(16))) u32 cm[ST_SUB][2 * ST_W32 + 4];   // partner j: UN words 0..31, DN words 0..31 (zero
                                                                                 // beyond W32); rows padded by 16 bytes: the survivors'
                                                                                 // per-lane rows fall on different banks
@@ -219,6 +220,12 @@ __global__ __launch_bounds__(ST_THREADS) void strict_pairs2_kernel(
         un[w] = (alive && w < W32) ? mb[(size_t)w * n + a] : 0u;
         dn[w] = (alive && w < W32) ? mb[(size_t)(W32 + w) * n + a] : 0u;
     }
+    // a curve that is never above the target (UN empty) cannot conflict with one that is never below it (DN empty):
+    // such pairs -- most of the contained pairs of banded data -- need no walk over the masks
+    u32 ora = 0, ord_ = 0;
+#pragma unroll
+    for (int w = 0; w < ST_W32; ++w) { ora |= un[w]; ord_ |= dn[w]; }
+    const bool u0a = ora == 0, d0a = ord_ == 0;
     u64 good = 0;
     for (i64 s0 = b0; s0 < b1; s0 += ST_SUB) {
         const int len = (int)(b1 - s0 < ST_SUB ? b1 - s0 : ST_SUB);
@@ -231,6 +238,27 @@ __global__ __launch_bounds__(ST_THREADS) void strict_pairs2_kernel(
             cm[j][w2] = v;
         }
         __syncthreads();
+        // which partners have an empty UN / DN mask: wave w ORs words 8w..8w+7 of partner j = lane, the four waves meet in LDS
+        {
+            const int j = threadIdx.x & 63, part = threadIdx.x >> 6;
+            u32 pu = 0, pd = 0;
+#pragma unroll
+            for (int w = 0; w < 8; w += 4) {
+                const uint4 cu = *reinterpret_cast<const uint4 *>(&cm[j][part * 8 + w]);
+                const uint4 cd = *reinterpret_cast<const uint4 *>(&cm[j][ST_W32 + part * 8 + w]);
+                pu |= cu.x | cu.y | cu.z | cu.w;
+                pd |= cd.x | cd.y | cd.z | cd.w;
+            }
+            orparts[part][0][j] = pu;
+            orparts[part][1][j] = pd;
+        }
+        __syncthreads();
+        u64 U0, D0;                                             // bit j: partner j has no UN / no DN bit (wave-uniform)
+        {
+            const int j = threadIdx.x & 63;
+            U0 = __ballot((orparts[0][0][j] | orparts[1][0][j] | orparts[2][0][j] | orparts[3][0][j]) == 0);
+            D0 = __ballot((orparts[0][1][j] | orparts[1][1][j] | orparts[2][1][j] | orparts[3][1][j]) == 0);
+        }
         // ---- pass 1: first four words of every partner; survivors as bits ----
         u64 surv = 0;
 #pragma unroll 8
@@ -251,6 +279,10 @@ __global__ __launch_bounds__(ST_THREADS) void strict_pairs2_kernel(
         if (W32 <= 4) {
             good += (u64)__popcll(surv);
         } else {
+            // pairs that cannot conflict by class: counted without the walk
+            const u64 sure = surv & ((u0a ? D0 : 0ull) | (d0a ? U0 : 0ull));
+            good += (u64)__popcll(sure);
+            surv &= ~sure;
             // ---- pass 2: the survivors' remaining words ----
             while (surv) {
                 const int j = __ffsll((long long)surv) - 1;
