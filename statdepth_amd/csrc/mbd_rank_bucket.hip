@@ -34,6 +34,13 @@ namespace sd {
 
 constexpr u32 RB_AB_SPECIAL = 0xFFFFFFFFu;     // same encodings as mbd_rank_ab.hip
 constexpr u32 RB_ROW_DEFERRED = 0xFFFFFFFFu;
+// RB_SMALL_E > 0 builds the kernels with at most that many keys per thread for 64 VGPRs and launches two workgroups
+// (two rows) per CU.  Measured (n = 600..4096, T = 1000): no faster than one workgroup per CU -- the kernel is bound
+// by VALU + LDS throughput, not by latency or barrier stalls -- so it is off.
+#ifndef RB_SMALL_E
+#define RB_SMALL_E 0
+#endif
+#define RB_WAVES_PER_EU(E) ((E) <= RB_SMALL_E ? 8 : 4)
 #ifndef RB_INFLIGHT
 #define RB_INFLIGHT 2
 #endif
@@ -128,7 +135,7 @@ struct RBCfg {
 // DBG (timing experiments only, results invalid): 1 = stop after the range, 2 = after the histogram, 3 = after the
 // prefix sum, 4 = after the scatter
 template <int NT, int E, int LNB, int J, int CAP, int U2, int DBG = 0>
-__global__ __launch_bounds__(NT) void rank_bucket_kernel(const double *__restrict__ Y, i64 n64, i64 row0, i64 rows,
+__global__ __launch_bounds__(NT, RB_WAVES_PER_EU(E)) void rank_bucket_kernel(const double *__restrict__ Y, i64 n64, i64 row0, i64 rows,
                                                          u64 *__restrict__ partial, int p32) {
     using C = RBCfg<NT, E, LNB, U2>;
     constexpr int NB = C::NB, NW = C::NW, QW = C::QW;
@@ -532,7 +539,7 @@ bool mbd_rank_bucket_supported(i64 T, i64 n, int J) {
 }
 
 // upper bound of the grid the launcher will use (the partial totals are sized by it)
-int mbd_rank_bucket_max_grid() { return rb_cus(); }
+int mbd_rank_bucket_max_grid() { return 2 * rb_cus(); }
 
 size_t mbd_rank_bucket_workspace_bytes(i64 rows, i64 n, int J) {
     return align_up((size_t)mbd_rank_bucket_max_grid() * (J - 1) * n * 8, 256) + align_up((size_t)rows, 256) + 512;
@@ -604,7 +611,8 @@ static int launch_bucket_j(const double *Y, i64 n, i64 row0, i64 rows, u64 *part
 // rows [row0, row0 + rows): bucket kernel; returns the grid used (number of partial blocks) in *G_out
 int launch_rank_bucket(const double *Y, i64 n, i64 row0, i64 rows, int J, u64 *partial, int *p32_out, int *G_out,
                        hipStream_t s) {
-    const int cus = mbd_rank_bucket_max_grid();
+    // one workgroup per CU; two where the kernel is built for 64 VGPRs (few keys per thread)
+    const int cus = rb_cus() * (((n + 1023) / 1024) <= RB_SMALL_E ? 2 : 1);
     const int G = (int)(rows < cus ? rows : cus);
     *G_out = G;
     if (rows > (i64)G * 2048) return fail(SD_ERR_INVALID, "bucket kernel: more than 2048 rows per workgroup in one launch");
