@@ -196,7 +196,7 @@ __global__ __launch_bounds__(1024) void bucket_partition_kernel(const double *__
                                                                 const double *__restrict__ spl,
                                                                 u32 *__restrict__ bcnt, u32 *__restrict__ nnanrow,
                                                                 u32 *__restrict__ ovf, double *__restrict__ bval,
-                                                                u32 *__restrict__ bidx, AB2 *__restrict__ ab) {
+                                                                u32 *__restrict__ bidx, AB2 *__restrict__ ab, int dbg) {
     __shared__ double s_spl[BK_MAXNB];
     __shared__ u32 s_hist[BK_MAXNB];
     __shared__ u32 s_base[BK_MAXNB];
@@ -225,6 +225,7 @@ __global__ __launch_bounds__(1024) void bucket_partition_kernel(const double *__
             if (x[e] == x[e]) {
                 // bucket = number of splitters < x (equal values always share a bucket)
                 int lo = 0, hi = NB - 1;
+                if (dbg) lo = hi = (int)((u32)(e + t) % (u32)NB);     // timing experiment: no search (results invalid)
                 while (lo < hi) {
                     const int mid = (lo + hi) >> 1;
                     if (s_spl[mid] < x[e]) lo = mid + 1;
@@ -258,6 +259,110 @@ __global__ __launch_bounds__(1024) void bucket_partition_kernel(const double *__
             } else {
                 over = true;
             }
+        }
+    }
+    if (over) ovf[rb] = 1u;
+}
+
+// P' (default): the same partition with the scatter staged through LDS.  One workgroup takes 8 192 consecutive curves
+// of one row, orders them by value bucket inside LDS (local slot = LDS-atomic offset + local exclusive prefix of the
+// workgroup's bucket counts) and copies the ordered block out: consecutive threads write consecutive elements of a
+// bucket's run, so the 12-byte records leave as coalesced stores instead of ~19 interleaved partial runs per wave
+// instruction.  grid = (ceil(n / 8192), rows).
+constexpr int BP2_NT = 1024, BP2_E = 8, BP2_C = BP2_NT * BP2_E;
+__global__ __launch_bounds__(BP2_NT) void bucket_partition2_kernel(const double *__restrict__ Y, i64 n, i64 row0, int NB,
+                                                                   const double *__restrict__ spl,
+                                                                   u32 *__restrict__ bcnt, u32 *__restrict__ nnanrow,
+                                                                   u32 *__restrict__ ovf, double *__restrict__ bval,
+                                                                   u32 *__restrict__ bidx, AB2 *__restrict__ ab) {
+    extern __shared__ double Sm2[];
+    double *Skey = Sm2;                                               // [BP2_C]
+    u32 *Sid = reinterpret_cast<u32 *>(Skey + BP2_C);                 // [BP2_C]
+    unsigned short *Sbk = reinterpret_cast<unsigned short *>(Sid + BP2_C);   // [BP2_C]
+    __shared__ double s_spl[BK_MAXNB];
+    __shared__ u32 s_hist[BK_MAXNB];
+    __shared__ u32 s_gbase[BK_MAXNB];
+    __shared__ u32 s_lbase[BK_MAXNB + 1];
+    __shared__ u32 s_wtot[BP2_NT / 64];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const i64 rb = blockIdx.y;
+    const i64 base = (i64)blockIdx.x * BP2_C;
+    for (int b = t; b < BK_MAXNB; b += BP2_NT) {
+        if (b < NB - 1) s_spl[b] = spl[rb * (NB - 1) + b];
+        s_hist[b] = 0;
+    }
+    __syncthreads();
+    const double *row = Y + (row0 + rb) * n;
+    double x[BP2_E];
+    u32 bk[BP2_E], off[BP2_E];
+    u32 mynan = 0;
+#pragma unroll
+    for (int e = 0; e < BP2_E; ++e) {
+        const i64 i = base + t + e * BP2_NT;
+        x[e] = (i < n) ? row[i] : 0.0;
+    }
+#pragma unroll
+    for (int e = 0; e < BP2_E; ++e) {
+        const i64 i = base + t + e * BP2_NT;
+        bk[e] = 0xFFFFFFFFu;
+        off[e] = 0;
+        if (i < n) {
+            if (x[e] == x[e]) {
+                int lo = 0, hi = NB - 1;                    // bucket = number of splitters < x (equal values share a bucket)
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    if (s_spl[mid] < x[e]) lo = mid + 1;
+                    else hi = mid;
+                }
+                bk[e] = (u32)lo;
+                off[e] = atomicAdd(&s_hist[lo], 1u);
+            } else {
+                ++mynan;
+                AB2 v;
+                v.B = AB2_NAN;
+                v.A = 0;
+                ab[rb * n + i] = v;
+            }
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) mynan += __shfl_down(mynan, o);
+    if (lane == 0 && mynan) atomicAdd(&nnanrow[rb], mynan);
+    __syncthreads();
+    // global base of this workgroup's run in every bucket; local exclusive prefix of the counts (one thread per bucket)
+    {
+        const u32 c = (t < NB) ? s_hist[t] : 0u;
+        if (t < NB) s_gbase[t] = c ? atomicAdd(&bcnt[rb * NB + t], c) : 0u;
+        const u32 incl = rb_wave_incl_scan(c);
+        if (lane == 63) s_wtot[wave] = incl;
+        __syncthreads();
+        const u32 wt = (lane < BP2_NT / 64) ? s_wtot[lane] : 0u;
+        const u32 wscan = rb_row_incl_scan(wt);
+        const u32 woff = wave ? rb_readlane(wscan, wave - 1) : 0u;
+        if (t < NB) s_lbase[t] = woff + incl - c;
+        if (t == BP2_NT - 1) s_lbase[NB] = woff + incl;             // number of non-NaN keys of the block (NB <= 1024)
+    }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < BP2_E; ++e) {
+        if (bk[e] != 0xFFFFFFFFu) {
+            const u32 lp = s_lbase[bk[e]] + off[e];
+            Skey[lp] = x[e];
+            Sid[lp] = (u32)(base + t + e * BP2_NT);
+            Sbk[lp] = (unsigned short)bk[e];
+        }
+    }
+    __syncthreads();
+    const u32 nval = s_lbase[NB];
+    bool over = false;
+    for (u32 p = t; p < nval; p += BP2_NT) {
+        const u32 b = Sbk[p];
+        const u32 g = s_gbase[b] + (p - s_lbase[b]);
+        if (g < (u32)BK_C) {
+            const size_t slot = ((size_t)rb * NB + b) * BK_C + g;
+            bval[slot] = Skey[p];
+            bidx[slot] = Sid[p];
+        } else {
+            over = true;
         }
     }
     if (over) ovf[rb] = 1u;
@@ -769,6 +874,8 @@ int launch_mbd_rank_big(const double *Y, i64 T, i64 n, const i64 *targets, i64 t
     SD_HIP(hipFuncSetAttribute((const void *)k_sp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SsCfg::LDS_BYTES));
     SD_HIP(hipFuncSetAttribute((const void *)k_bp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bk));
     SD_HIP(hipFuncSetAttribute((const void *)k_br, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BR_LDS));
+    SD_HIP(hipFuncSetAttribute((const void *)bucket_partition2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)((size_t)BP2_C * 14)));
     SD_HIP(hipFuncSetAttribute((const void *)k_bs, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BkCfg::LDS_BYTES));
 
     for (i64 row0 = 0; row0 < T; row0 += p.rpb) {
@@ -778,8 +885,14 @@ int launch_mbd_rank_big(const double *Y, i64 T, i64 n, const i64 *targets, i64 t
         const u32 *nn_for_fold = nanf;
         if (buckets) {
             hipLaunchKernelGGL(k_sp, dim3((unsigned)rows), dim3(256), SsCfg::LDS_BYTES, s, Y, n, row0, NB, spl);
-            hipLaunchKernelGGL(bucket_partition_kernel, dim3((unsigned)((n + 16383) / 16384), (unsigned)rows), dim3(1024), 0,
-                               s, Y, n, row0, NB, (const double *)spl, bcnt, nnanrow, ovf, bval, bidx, ab);
+            const char *ep = getenv("SD_BIG_PART1");             // 1: first-generation partition (direct scatter), cross-check
+            if (ep && atoi(ep) == 1)
+                hipLaunchKernelGGL(bucket_partition_kernel, dim3((unsigned)((n + 16383) / 16384), (unsigned)rows), dim3(1024),
+                                   0, s, Y, n, row0, NB, (const double *)spl, bcnt, nnanrow, ovf, bval, bidx, ab, 0);
+            else
+                hipLaunchKernelGGL(bucket_partition2_kernel, dim3((unsigned)((n + BP2_C - 1) / BP2_C), (unsigned)rows),
+                                   dim3(BP2_NT), (size_t)BP2_C * 14, s, Y, n, row0, NB, (const double *)spl, bcnt, nnanrow,
+                                   ovf, bval, bidx, ab);
             if (rank_nosort)
                 hipLaunchKernelGGL(k_br, dim3((unsigned)(8 * NB * ((rows + 7) / 8))), dim3(BR_NT), BR_LDS, s, n, rows, NB,
                                    (const u32 *)bcnt,
