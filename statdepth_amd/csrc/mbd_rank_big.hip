@@ -153,21 +153,26 @@ __global__ __launch_bounds__(BIG_NT) void chunk_search_kernel(const double *__re
 constexpr int BK_NT = 512, BK_E = 16;
 constexpr int BK_C = BK_NT * BK_E;             // bucket capacity 8192
 constexpr int BK_FILL = 5500;                  // target mean fill
-constexpr int BK_SS = 4096;                    // sample size (sorted by one 256-thread workgroup)
 constexpr int BK_MAXNB = 1024;
 using BkCfg = R2Cfg<BK_NT, BK_E>;
-using SsCfg = R2Cfg<256, 16>;
 
 static inline int bucket_count(i64 n) {
-    i64 nb = (n + BK_FILL - 1) / BK_FILL;
+    // mean fill 5 500 of 8 192; past ~300 buckets even the 16 384-value sample leaves < 50 samples per bucket and the
+    // fills scatter too much: aim lower
+    const i64 fill = n > 1600000 ? 3800 : BK_FILL;
+    i64 nb = (n + fill - 1) / fill;
     if (nb < 2) nb = 2;
     return (int)nb;
 }
 
-// S: grid = rows; spl[r][0..NB-2] ascending
-__global__ __launch_bounds__(256) void bucket_splitters_kernel(const double *__restrict__ Y, i64 n, i64 row0, int NB,
+// S: grid = rows; spl[r][0..NB-2] ascending.  SNT threads sort a strided sample of 16 SNT values: 4 096 for up to 72
+// value buckets, 16 384 above (a bucket's fill scatters with 1 / sqrt(samples per bucket); at n = 10^6 the small
+// sample overflowed the 8 192-key buckets and sent every row to the chunked route).
+template <int SNT>
+__global__ __launch_bounds__(SNT) void bucket_splitters_kernel(const double *__restrict__ Y, i64 n, i64 row0, int NB,
                                                                double *__restrict__ spl) {
-    constexpr int E = 16, LE = SsCfg::LE;
+    using Cfg = R2Cfg<SNT, 16>;
+    constexpr int E = 16, LE = Cfg::LE, SS = SNT * 16;
     extern __shared__ double Sm[];
     const int t = threadIdx.x;
     const i64 rb = blockIdx.x;
@@ -177,16 +182,16 @@ __global__ __launch_bounds__(256) void bucket_splitters_kernel(const double *__r
 #pragma unroll
     for (int e = 0; e < E; ++e) {
         const i64 s = (i64)t * E + e;                       // sample index, any assignment of samples to slots works
-        double v = row[(s * n) / BK_SS];
+        double v = row[(s * n) / SS];
         k[e] = (v == v) ? v : INF;
     }
-    R2Sorter<256, 16>::sort(k, Sm, t, BK_SS, true, INF);
+    R2Sorter<SNT, 16>::sort(k, Sm, t, SS, true, INF);
     double *Sw = Sm + r2_base<0, LE>(t);
 #pragma unroll
     for (int e = 0; e < E; ++e) Sw[r2_off<0, LE>(e)] = k[e];
     __syncthreads();
-    for (int b = t; b < NB - 1; b += 256) {
-        const int q = (int)(((i64)(b + 1) * BK_SS) / NB);
+    for (int b = t; b < NB - 1; b += SNT) {
+        const int q = (int)(((i64)(b + 1) * SS) / NB);
         spl[rb * (NB - 1) + b] = Sm[r2_phys<LE>(q)];
     }
 }
@@ -862,7 +867,9 @@ int launch_mbd_rank_big(const double *Y, i64 T, i64 n, const i64 *targets, i64 t
     }
     auto k_cs = chunk_sort_kernel;
     auto k_cq = chunk_search_kernel;
-    auto k_sp = bucket_splitters_kernel;
+    auto k_sp = bucket_splitters_kernel<256>;
+    auto k_sp_big = bucket_splitters_kernel<1024>;
+    constexpr size_t lds_sp = R2Cfg<256, 16>::LDS_BYTES, lds_sp_big = R2Cfg<1024, 16>::LDS_BYTES;
     auto k_bp = bucket_packed_kernel;
     auto k_br = bucket_rank_kernel;
     const char *envA = getenv("SD_BIG_SORT");                 // 1: packed-key sort per value bucket (predecessor, cross-check)
@@ -871,7 +878,9 @@ int launch_mbd_rank_big(const double *Y, i64 T, i64 n, const i64 *targets, i64 t
     const size_t lds_bk = BkCfg::LDS_BYTES + (size_t)BK_NT * 8;
     SD_HIP(hipFuncSetAttribute((const void *)k_cs, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BigCfg::LDS_BYTES));
     SD_HIP(hipFuncSetAttribute((const void *)k_cq, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BigCfg::LDS_BYTES));
-    SD_HIP(hipFuncSetAttribute((const void *)k_sp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SsCfg::LDS_BYTES));
+    SD_HIP(hipFuncSetAttribute((const void *)k_sp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sp));
+    SD_HIP(hipFuncSetAttribute((const void *)k_sp_big, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)lds_sp_big));
     SD_HIP(hipFuncSetAttribute((const void *)k_bp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bk));
     SD_HIP(hipFuncSetAttribute((const void *)k_br, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BR_LDS));
     SD_HIP(hipFuncSetAttribute((const void *)bucket_partition2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -884,7 +893,10 @@ int launch_mbd_rank_big(const double *Y, i64 T, i64 n, const i64 *targets, i64 t
         const u32 *fallback_rows = nullptr;                  // chunked route: every row
         const u32 *nn_for_fold = nanf;
         if (buckets) {
-            hipLaunchKernelGGL(k_sp, dim3((unsigned)rows), dim3(256), SsCfg::LDS_BYTES, s, Y, n, row0, NB, spl);
+            if (NB <= 72)
+                hipLaunchKernelGGL(k_sp, dim3((unsigned)rows), dim3(256), lds_sp, s, Y, n, row0, NB, spl);
+            else
+                hipLaunchKernelGGL(k_sp_big, dim3((unsigned)rows), dim3(1024), lds_sp_big, s, Y, n, row0, NB, spl);
             const char *ep = getenv("SD_BIG_PART1");             // 1: first-generation partition (direct scatter), cross-check
             if (ep && atoi(ep) == 1)
                 hipLaunchKernelGGL(bucket_partition_kernel, dim3((unsigned)((n + 16383) / 16384), (unsigned)rows), dim3(1024),

@@ -451,6 +451,19 @@ def test_config3_scale_properties(eng, oracle):
     assert (blk == full[37500:50000]).all()
 
 
+def test_million_points_linf_shape(eng, oracle):
+    """BASELINE.json configs[4] in its L-infinity form: 10^6 points in R^3 = 10^6 "curves" x 3 "timepoints"
+    (SURVEY.md 8 P4): the large-n route with 182 value buckets per row, against the oracle and the pairwise kernel."""
+    rng = np.random.default_rng(1237)
+    X = np.ascontiguousarray(rng.normal(size=(1_000_000, 3)).T)
+    tg = np.array([0, 1, 499_999, 777_777, 999_999, 123_456])
+    want = oracle.mbd_counts(X, tg, 2)
+    assert (eng.mbd_counts(X, tg, 2, algo="rank") == want).all()
+    assert (eng.mbd_counts(X, tg, 2, algo="pairwise") == want).all()
+    Xt = np.round(X, 2)                                    # ties: ~600 distinct values per coordinate
+    assert (eng.mbd_counts(Xt, tg, 2, algo="rank") == oracle.mbd_counts(Xt, tg, 2)).all()
+
+
 def test_row_batching(eng, oracle, monkeypatch):
     """Rows are processed in batches when the pair image / sorted scratch would exceed 1 GiB; force small batches."""
     rng = np.random.default_rng(77)
