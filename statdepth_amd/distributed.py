@@ -226,6 +226,50 @@ def sharded_mbd_counts(X_loc, J=2, algo="auto", group=None, gather_result=False,
     return torch.cat([recv[r, :int(sizes[r])] for r in range(world)], dim=0)
 
 
+def gather_point_blocks(P_loc, group=None):
+    """All-gather of per-rank point blocks [n_loc, d] (ragged n_loc allowed).  Returns (P_all [n, d], offsets)."""
+    import torch
+    dist = _dist()
+    world = dist.get_world_size(group)
+    n_loc, d = P_loc.shape
+    szt = torch.zeros(world, dtype=torch.int64, device=P_loc.device)
+    dist.all_gather_into_tensor(szt, torch.tensor([n_loc], dtype=torch.int64, device=P_loc.device), group=group)
+    sizes = [int(v) for v in szt.cpu().tolist()]
+    offsets = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    nmax = max(sizes)
+    send = torch.zeros((nmax, d), dtype=P_loc.dtype, device=P_loc.device)
+    send[:n_loc].copy_(P_loc)
+    recv = torch.empty((world * nmax, d), dtype=P_loc.dtype, device=P_loc.device)
+    dist.all_gather_into_tensor(recv, send.contiguous(), group=group)
+    recv = recv.view(world, nmax, d)
+    P_all = torch.cat([recv[r, :sizes[r]] for r in range(world)], dim=0).contiguous()
+    return P_all, offsets
+
+
+def _default_pointcloud_compute(P_all, targets, containment, samples, seed):
+    """HIP path (device tensors in, numpy out)."""
+    if containment == "l1":
+        return engine.l1_depth(P_all, targets)
+    return engine.pointcloud_simplex_counts(P_all, targets, samples=samples, seed=seed)
+
+
+def sharded_pointcloud(P_loc, containment="simplex", samples=None, seed=0, group=None, _compute=None):
+    """Point-cloud depth quantities of this rank's points against the union of all ranks' points.
+
+    The reference's target loop (_pointcloud.py:45) carries no state: rank r owns a block of points, the blocks are
+    all-gathered once (RCCL over xGMI; a 10^6 x 3 cloud is 24 MB) and every rank runs the kernel for its own targets.
+    containment "simplex": containment counts (int64; exhaustive, or `samples` seeded subsets per point -- the subset
+    draws are keyed by the GLOBAL point index, so the result does not depend on the sharding); "l1": L1 depths (fp64).
+    Returns (values of the local points, n_total).  `_compute` is a test hook (CPU/gloo tests inject the oracle).
+    """
+    dist = _dist()
+    rank = dist.get_rank(group)
+    P_all, offsets = gather_point_blocks(P_loc, group)
+    targets = np.arange(offsets[rank], offsets[rank + 1], dtype=np.int64)
+    compute = _compute or _default_pointcloud_compute
+    return compute(P_all, targets, containment, samples, seed), int(offsets[-1])
+
+
 def sharded_functional_depth(df_local, J=2, relax=True, algo="auto", group=None, mode="auto", _compute=None,
                              _compute_all=None):
     """FunctionalDepth over curves sharded by column blocks: returns this rank's depth Series.

@@ -93,3 +93,60 @@ def test_sharded_equals_single(splits, J):
         assert (full == want).all()
         assert list(ser.index) == [f"c{i}" for i in range(lo, hi)]
         assert np.max(np.abs(ser.to_numpy() - wantd[lo:hi])) <= 1e-12
+
+
+def _pc_oracle(P_all, targets, containment, samples, seed):
+    import oracle
+    P = P_all.cpu().numpy()
+    if containment == "l1":
+        return oracle.l1_depth(P, targets)
+    if samples is None:
+        return oracle.pointcloud_simplex_counts(P, targets)
+    return oracle.simplex_sampled(P, targets, samples=samples, seed=seed)
+
+
+def _pc_worker(rank, world, port, splits, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from statdepth_amd.distributed import sharded_pointcloud
+        rng = np.random.default_rng(7)
+        P = rng.normal(size=(splits[-1], 2))
+        lo, hi = splits[rank], splits[rank + 1]
+        P_loc = torch.from_numpy(np.ascontiguousarray(P[lo:hi]))
+        ex, n1 = sharded_pointcloud(P_loc, "simplex", _compute=_pc_oracle)
+        sm, n2 = sharded_pointcloud(P_loc, "simplex", samples=50, seed=3, _compute=_pc_oracle)
+        l1, n3 = sharded_pointcloud(P_loc, "l1", _compute=_pc_oracle)
+        assert n1 == n2 == n3 == splits[-1]
+        q.put((rank, np.asarray(ex), np.asarray(sm), np.asarray(l1)))
+    except Exception as e:
+        q.put((rank, repr(e), None, None))
+        raise
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("splits", [[0, 9, 18], [0, 4, 11, 19]])
+def test_sharded_pointcloud_equals_single(splits):
+    import oracle
+    world = len(splits) - 1
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_pc_worker, args=(r, world, port, splits, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    P = np.random.default_rng(7).normal(size=(splits[-1], 2))
+    want_ex = oracle.pointcloud_simplex_counts(P)
+    want_sm = oracle.simplex_sampled(P, np.arange(splits[-1]), samples=50, seed=3)
+    want_l1 = oracle.l1_depth(P)
+    for rank, ex, sm, l1 in res:
+        assert not isinstance(ex, str), ex
+        lo, hi = splits[rank], splits[rank + 1]
+        assert (ex == want_ex[lo:hi]).all() and (sm == want_sm[lo:hi]).all()
+        assert np.max(np.abs(l1 - want_l1[lo:hi])) <= 1e-12

@@ -464,6 +464,36 @@ def test_million_points_linf_shape(eng, oracle):
     assert (eng.mbd_counts(Xt, tg, 2, algo="rank") == oracle.mbd_counts(Xt, tg, 2)).all()
 
 
+def test_sharded_paths_world_size_one(eng, oracle):
+    """The multi-GPU paths on RCCL with a single rank: all-to-all / reduce-scatter (curves) and all-gather (points) run,
+    the HIP engine is the compute hook, results equal the single-process calls."""
+    import os
+    import socket
+    import torch
+    import torch.distributed as dist
+    from statdepth_amd.distributed import sharded_mbd_counts, sharded_pointcloud
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
+    dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+    try:
+        rng = np.random.default_rng(12)
+        X = np.round(rng.normal(size=(23, 500)).cumsum(axis=0), 1)
+        Xd = torch.from_numpy(X).cuda()
+        want = oracle.mbd_counts(X, None, 2)
+        for mode in ("time", "targets"):
+            assert (sharded_mbd_counts(Xd, J=2, mode=mode).cpu().numpy() == want).all()
+        P = rng.normal(size=(40, 3))
+        Pd = torch.from_numpy(P).cuda()
+        got, n = sharded_pointcloud(Pd, "simplex")
+        assert n == 40 and (np.asarray(got) == eng.pointcloud_simplex_counts(P)).all()
+        got, _ = sharded_pointcloud(Pd, "simplex", samples=64, seed=5)
+        assert (np.asarray(got) == oracle.simplex_sampled(P, np.arange(40), samples=64, seed=5)).all()
+        got, _ = sharded_pointcloud(Pd, "l1")
+        assert np.max(np.abs(np.asarray(got) - oracle.l1_depth(P))) <= TOL
+    finally:
+        dist.destroy_process_group()
+
+
 def test_row_batching(eng, oracle, monkeypatch):
     """Rows are processed in batches when the pair image / sorted scratch would exceed 1 GiB; force small batches."""
     rng = np.random.default_rng(77)
