@@ -105,6 +105,9 @@ int sd_mbd_counts_range(const double *X, int64_t T, int64_t n, int64_t st, int64
  * depth of g within F u {g} = sum_j out/T / C(n+1, j) on the host (_functional.py:229,253). */
 int sd_mbd_external_counts(const double *X, int64_t T, int64_t n, const double *Q, int64_t m, int J,
                            int64_t *out, void *ws, size_t ws_bytes, void *stream);
+/* Workspace for sd_mbd_external_counts.  With at least this much the call ranks the targets through a per-row bucket
+ * structure (O(n + m) per timepoint, n <= 16384, J <= 3); with T*4 + 256 bytes it still works (pairwise, O(n m)). */
+size_t sd_mbd_external_workspace_bytes(int64_t T, int64_t n, int64_t m, int J);
 
 /* Band totals of one target inside an explicit subset of the curves, for nb (subset, target) pairs in one launch:
  * the K-block sampled estimator (_samplefunctionaldepth, _functional.py:170-182) evaluates

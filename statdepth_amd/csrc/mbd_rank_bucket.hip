@@ -459,6 +459,186 @@ __global__ __launch_bounds__(NT, RB_WAVES_PER_EU(E)) void rank_bucket_kernel(con
 }
 
 // ---------------------------------------------------------------------------------------------------
+// X: band totals of EXTERNAL curves (targets that are not members of the set; the homogeneity coefficients'
+// `FunctionalDepth(F u {g}, to_compute=[g])`, homogeneity.py:101-128) through the same bucket structure.  Per row the
+// set is histogrammed, prefix-summed and scattered exactly as in rank_bucket_kernel; then every external value x looks
+// up its own bucket -- b(x) is monotone, so the keys of earlier buckets are below x and those of later ones above --
+// and compares itself with that bucket's members: B = base + #(y < x), A = n_valid - base - #(y <= x).  O(n + m)
+// per row instead of the pairwise kernel's O(n m).  No row is set aside: a row the map cannot spread (equal values,
+// an infinity) simply lands in one bucket, and m targets walking n keys is still cheap.
+// Thread t owns targets t, t + 1024, ... (EQ of them) and their totals for the whole launch.
+// ---------------------------------------------------------------------------------------------------
+template <int NT, int E, int LNB, int J, int EQ>
+__global__ __launch_bounds__(NT) void rank_external_kernel(const double *__restrict__ Y, i64 n64, i64 rows,
+                                                           const double *__restrict__ Q, i64 m64, i64 qstride,
+                                                           u64 *__restrict__ partial) {
+    using C = RBCfg<NT, E, LNB, 3>;
+    constexpr int NB = C::NB, NW = C::NW, QW = C::QW;
+    extern __shared__ double Sm[];
+    const int n = (int)n64, m = (int)m64;
+    double *red = Sm;                                                 // [2][NW][2] min/max partials
+    u32 *wtot = reinterpret_cast<u32 *>(red + 4 * NW);                // [NW]
+    u32 *H = reinterpret_cast<u32 *>(Sm + C::HDR / 8);                // NB packed u16 counters, then bases
+    double *S = reinterpret_cast<double *>(H + NB / 2 + 4);           // keys in bucket order
+    const unsigned short *H16 = reinterpret_cast<const unsigned short *>(H);
+    const int t0 = threadIdx.x;
+    const double INF = __builtin_huge_val();
+    const double QNAN = __builtin_nan("");
+    const int DUMMY = C::dummy_pos(n);
+    int t = t0;
+    {
+        uint4 *Hq = reinterpret_cast<uint4 *>(H);
+#pragma unroll
+        for (int i = 0; i < QW; ++i) Hq[i * NT + t] = make_uint4(0, 0, 0, 0);
+        if (t < 4) H[NB / 2 + t] = 0;
+    }
+    double k[E];
+    auto load_row = [&](i64 r) {
+        const double *rp = Y + r * n + t;
+#pragma unroll
+        for (int e = 0; e < E; ++e) k[e] = (e < E - 1 || t + (E - 1) * NT < n) ? rp[e * NT] : QNAN;
+    };
+    u64 acc[EQ][JMAX - 1];
+#pragma unroll
+    for (int q = 0; q < EQ; ++q)
+#pragma unroll
+        for (int j = 0; j < JMAX - 1; ++j) acc[q][j] = 0;
+    int par = 0;
+    if ((i64)blockIdx.x < rows) load_row(blockIdx.x);
+    for (i64 r = blockIdx.x; r < rows; r += gridDim.x) {
+        const i64 rnext = r + gridDim.x;
+        t = t0;
+        asm volatile("" : "+v"(t));                                   // per-row opaque thread id (see rank_bucket_kernel)
+        const int lane = t & 63;
+        const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+        // the row's external values (in flight under the set's phases)
+        double xq[EQ];
+#pragma unroll
+        for (int q = 0; q < EQ; ++q) xq[q] = (t + q * NT < m) ? Q[r * qstride + t + q * NT] : QNAN;
+        // ---- (0) range ----
+        double mn = INF, mx = -INF;
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            mn = rb_mm<false>(mn, k[e]);
+            mx = rb_mm<true>(mx, k[e]);
+        }
+        mn = rb_wave_allreduce<false>(mn);
+        mx = rb_wave_allreduce<true>(mx);
+        double *redp = red + par * 2 * NW;
+        if (lane == 63) { redp[2 * wave] = mn; redp[2 * wave + 1] = mx; }
+        par ^= 1;
+        __syncthreads();                                              // barrier 1
+        double lo, hi;
+        {
+            const double2 p = reinterpret_cast<const double2 *>(redp)[lane & 15];
+            lo = rb_readlane_f64(rb_row_allreduce<false>(p.x), 0);
+            hi = rb_readlane_f64(rb_row_allreduce<true>(p.y), 0);
+        }
+        double scale = (double)NB / (hi - lo);
+        // equal values, an infinity in the range, a range too small or too large: everything into one bucket
+        if (!((hi > lo) && (scale < INF) && (lo > -INF) && (hi < INF))) scale = 0.0;
+        auto bucket_of = [&](double x) {
+            double u = (x - lo) * scale;
+            u = u > 0.0 ? u : 0.0;                                    // below the range, and NaN (0 * inf) -> 0
+            u = u < (double)(NB - 1) ? u : (double)(NB - 1);
+            return (u32)u;
+        };
+        // ---- (1) histogram ----
+        u32 bs[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const double x = k[e];
+            u32 b = bucket_of(x);
+            b = (x == x) ? b : (u32)(NB + 2);
+            const u32 sh = (b & 1u) * 16u;
+            const u32 old = atomicAdd(&H[b >> 1], 1u << sh);
+            bs[e] = b | (((old >> sh) & 0xFFFFu) << 16);
+        }
+        __syncthreads();                                              // barrier 2
+        // ---- (2) exclusive prefix sum ----
+        {
+            uint4 *Hq = reinterpret_cast<uint4 *>(H) + wave * (64 * QW);
+            uint4 hq[QW];
+            u32 runq[QW], inclq[QW], offq[QW], wsum = 0;
+#pragma unroll
+            for (int i = 0; i < QW; ++i) {
+                hq[i] = Hq[i * 64 + lane];
+                const u32 lo16 = (hq[i].x & 0xFFFFu) + (hq[i].y & 0xFFFFu) + (hq[i].z & 0xFFFFu) + (hq[i].w & 0xFFFFu);
+                const u32 hi16 = (hq[i].x >> 16) + (hq[i].y >> 16) + (hq[i].z >> 16) + (hq[i].w >> 16);
+                runq[i] = lo16 + hi16;                                // counters reach n here: no packed addition
+                inclq[i] = rb_wave_incl_scan(runq[i]);
+                offq[i] = wsum;
+                wsum += rb_readlane(inclq[i], 63);
+            }
+            if (lane == 63) wtot[wave] = wsum;
+            __syncthreads();                                          // barrier 3
+            const u32 wscan = rb_row_incl_scan(wtot[lane & 15]);
+            const u32 woff = wave ? rb_readlane(wscan, wave - 1) : 0u;
+#pragma unroll
+            for (int i = 0; i < QW; ++i) {
+                u32 base = woff + offq[i] + inclq[i] - runq[i];
+                uint4 o;
+                o.x = base | ((base + (hq[i].x & 0xFFFFu)) << 16);
+                base += (hq[i].x & 0xFFFFu) + (hq[i].x >> 16);
+                o.y = base | ((base + (hq[i].y & 0xFFFFu)) << 16);
+                base += (hq[i].y & 0xFFFFu) + (hq[i].y >> 16);
+                o.z = base | ((base + (hq[i].z & 0xFFFFu)) << 16);
+                base += (hq[i].z & 0xFFFFu) + (hq[i].z >> 16);
+                o.w = base | ((base + (hq[i].w & 0xFFFFu)) << 16);
+                base += (hq[i].w & 0xFFFFu) + (hq[i].w >> 16);
+                Hq[i * 64 + lane] = o;
+                if (i == QW - 1 && t == NT - 1) H[NB / 2] = base;     // number of non-NaN keys
+            }
+        }
+        __syncthreads();                                              // barrier 4
+        // ---- (3) scatter ----
+        const u32 nv = H[NB / 2];
+        const u32 nn = (u32)n - nv;
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const u32 b = bs[e] & 0xFFFFu, slot = bs[e] >> 16;
+            const u32 base = H16[b];
+            S[(b < (u32)NB) ? base + slot : (u32)DUMMY] = k[e];
+        }
+        if (rnext < rows) load_row(rnext);
+        __syncthreads();                                              // barrier 5
+        // ---- (4x) every external value against the members of its bucket ----
+#pragma unroll
+        for (int q = 0; q < EQ; ++q) {
+            const double x = xq[q];
+            if (x == x) {                                             // NaN target (and target slots beyond m): nothing
+                const u32 b = bucket_of(x);
+                const u32 base = H16[b], end = H16[b + 1];
+                u32 less = 0, le = 0;
+                // a value outside the set's range sits in an end bucket and still compares correctly
+#pragma unroll 1
+                for (u32 j = base; j < end; ++j) {
+                    const double y = S[j];
+                    less += (y < x) ? 1u : 0u;
+                    le += (y <= x) ? 1u : 0u;
+                }
+                band_counts_add<J>(nv - base - le, base + less, nn, (u64)n, acc[q]);
+            }
+        }
+        __syncthreads();                                              // barrier 6: S and the bases have been read
+        {
+            uint4 *Hq = reinterpret_cast<uint4 *>(H) + wave * (64 * QW);
+#pragma unroll
+            for (int i = 0; i < QW; ++i) Hq[i * 64 + lane] = make_uint4(0, 0, 0, 0);
+        }
+    }
+    t = t0;
+    u64 *P = partial + (size_t)blockIdx.x * (J - 1) * m;
+#pragma unroll
+    for (int q = 0; q < EQ; ++q)
+        if (t + q * NT < m) {
+#pragma unroll
+            for (int j = 0; j < J - 1; ++j) P[(size_t)j * m + t + q * NT] = acc[q][j];
+        }
+}
+
+
+// ---------------------------------------------------------------------------------------------------
 // Z: out[q][j] (+)= sum_g partial[g][j][i(q)] + fold of the pair-image rows flagged in rowflag.
 // block = 32 targets x 32 slices (of workgroups g, of rows), LDS tree over the slices.  rowflag == nullptr: no pair image
 // (the bucket kernel ranks every row itself).
@@ -636,6 +816,66 @@ int launch_rank_finalize(const u64 *partial, int G, int p32, const u32 *AB, cons
         hipLaunchKernelGGL((rank_finalize_kernel<3>), grid, dim3(1024), 0, s, partial, G, p32, AB, nnan, rowflag, rows, n, targets,
                            tbegin, m, out, first);
     SD_HIP(hipGetLastError());
+    return SD_OK;
+}
+
+
+// ---- external targets through the bucket structure ----
+bool mbd_rank_external_supported(i64 T, i64 n, i64 m, int J) {
+    (void)T;
+    return n >= 2 && n <= 16384 && J >= 2 && J <= 3 && m >= 1;
+}
+
+size_t mbd_rank_external_workspace_bytes(i64 T, i64 n, i64 m, int J) {
+    if (!mbd_rank_external_supported(T, n, m, J)) return 0;
+    const i64 mc = m < 8192 ? m : 8192;
+    return align_up((size_t)rb_cus() * (J - 1) * mc * 8, 256) + 512;
+}
+
+template <int E, int LNB, int J>
+static int launch_external_cfg(const double *Y, i64 n, i64 rows, const double *Q, i64 m, i64 qstride, u64 *partial, int G,
+                               hipStream_t s) {
+    using C = RBCfg<1024, E, LNB, 3>;
+    const size_t lds = C::lds_bytes((int)n);
+    if (lds > 163840) return fail(SD_ERR_UNSUPPORTED, "external kernel: %zu bytes of LDS for n=%lld", lds, (long long)n);
+#define RB_XL(EQ_)                                                                                                  \
+    {                                                                                                                \
+        auto kf = rank_external_kernel<1024, E, LNB, J, EQ_>;                                                        \
+        SD_HIP(hipFuncSetAttribute((const void *)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));        \
+        hipLaunchKernelGGL(kf, dim3(G), dim3(1024), lds, s, Y, n, rows, Q, m, qstride, partial);                              \
+    }
+    if (m <= 1024) RB_XL(1) else if (m <= 2048) RB_XL(2) else if (m <= 4096) RB_XL(4) else RB_XL(8)
+#undef RB_XL
+    SD_HIP(hipGetLastError());
+    return SD_OK;
+}
+
+// Q: T x m time-major; out[q][j] = totals.  Targets go in groups of 8 192 (8 per thread).
+int launch_mbd_external_rank(const double *Y, i64 T, i64 n, const double *Q, i64 m, int J, u64 *out, void *ws,
+                             size_t ws_bytes, hipStream_t s) {
+    if (!mbd_rank_external_supported(T, n, m, J)) return fail(SD_ERR_UNSUPPORTED, "external rank kernel: unsupported shape");
+    if (!ws || ws_bytes < mbd_rank_external_workspace_bytes(T, n, m, J))
+        return fail(SD_ERR_WORKSPACE, "external rank workspace too small");
+    u64 *partial = (u64 *)(((size_t)ws + 255) / 256 * 256);
+    const int cus = rb_cus();
+    const int G = (int)(T < cus ? T : cus);
+    const int E = (int)((n + 1023) / 1024);
+    for (i64 q0 = 0; q0 < m; q0 += 8192) {
+        const i64 mc = m - q0 < 8192 ? m - q0 : 8192;
+        int rc = SD_OK;
+#define RB_XE(E_, L_) case E_: rc = (J == 2) ? launch_external_cfg<E_, L_, 2>(Y, n, T, Q + q0, mc, m, partial, G, s) \
+                                             : launch_external_cfg<E_, L_, 3>(Y, n, T, Q + q0, mc, m, partial, G, s); break;
+        switch (E) {
+            RB_XE(1, 13) RB_XE(2, 13) RB_XE(3, 13) RB_XE(4, 13) RB_XE(5, 14) RB_XE(6, 14) RB_XE(7, 14) RB_XE(8, 14)
+            RB_XE(9, 14) RB_XE(10, 14) RB_XE(11, 14) RB_XE(12, 14) RB_XE(13, 14) RB_XE(14, 14) RB_XE(15, 14) RB_XE(16, 13)
+            default: return fail(SD_ERR_UNSUPPORTED, "external rank kernel covers n <= 16384");
+        }
+#undef RB_XE
+        if (rc) return rc;
+        if ((rc = launch_rank_finalize(partial, G, 0, nullptr, nullptr, nullptr, T, mc, nullptr, 0, mc, J,
+                                       out + q0 * (J - 1), 1, s)))
+            return rc;
+    }
     return SD_OK;
 }
 

@@ -212,12 +212,24 @@ int sd_mbd_external_counts(const double *X, int64_t T, int64_t n, const double *
     int rc = check_count_range(T, n + 1, J);
     if (rc) return rc;
     if (m == 0) return SD_OK;
+    hipStream_t s = (hipStream_t)stream;
+    // bucket structure per row + one look-up per target (O(n + m) per row) when the caller gave the workspace for it
+    // (sd_mbd_external_workspace_bytes); the pairwise kernel (O(n m) per row) otherwise
+    if (mbd_rank_external_supported(T, n, m, J) && m >= 16 && ws &&
+        ws_bytes >= mbd_rank_external_workspace_bytes(T, n, m, J) + 256)
+        return launch_mbd_external_rank(X, T, n, Q, m, J, (u64 *)out, ws, ws_bytes, s);
     Carver cv(ws, ws_bytes);
     u32 *nan_cnt = (u32 *)cv.take((size_t)T * 4);
     if (!nan_cnt) return fail(SD_ERR_WORKSPACE, "workspace too small (need T*4 + 256 bytes)");
-    hipStream_t s = (hipStream_t)stream;
     if ((rc = launch_nan_count_rows(X, T, n, nan_cnt, s))) return rc;
     return launch_mbd_external(X, T, n, Q, m, J, nan_cnt, (u64 *)out, s);
+}
+
+size_t sd_mbd_external_workspace_bytes(int64_t T, int64_t n, int64_t m, int J) {
+    if (T <= 0 || n <= 0 || m <= 0) return 0;
+    size_t pw = align_up((size_t)T * 4, 256) + 256;                       // pairwise kernel: per-row NaN counts
+    size_t rk = mbd_rank_external_workspace_bytes(T, n, m, J);           // 0 where the bucket kernel does not apply
+    return (rk ? rk + 256 : 0) > pw ? rk + 256 : pw;
 }
 
 int sd_mbd_subset_counts(const double *X, int64_t T, int64_t n, const int32_t *members, int64_t nb, int bs,

@@ -61,6 +61,11 @@ size_t mbd_rank_workspace_bytes(i64 T, i64 n, int J);
 bool mbd_rank_supported(i64 T, i64 n, int J);
 int launch_mbd_rank(const double *Y, i64 T, i64 n, const i64 *targets, i64 tbegin, i64 m, int J,
                     u64 *out, void *ws, size_t ws_bytes, hipStream_t s);
+// external targets through the bucket structure (n <= 16384, J <= 3)
+bool mbd_rank_external_supported(i64 T, i64 n, i64 m, int J);
+size_t mbd_rank_external_workspace_bytes(i64 T, i64 n, i64 m, int J);
+int launch_mbd_external_rank(const double *Y, i64 T, i64 n, const double *Q, i64 m, int J, u64 *out, void *ws,
+                             size_t ws_bytes, hipStream_t s);
 // K1+K2 rank formulation for n > 16384 (chunked)
 bool mbd_rank_big_supported(i64 T, i64 n, int J);
 size_t mbd_rank_big_workspace_bytes(i64 T, i64 n, int J);

@@ -141,7 +141,7 @@ def mbd_external_counts(X, Q, J=2, device=None):
         raise ValueError("Q must have the same number of timepoints as X")
     m = Qd.shape[1]
     out = t.empty((m, J - 1), dtype=t.int64, device=dev)
-    wsb = T * 4 + 1024
+    wsb = int(lib.sd_mbd_external_workspace_bytes(T, n, m, J)) + 1024
     ws = t.empty(wsb, dtype=t.uint8, device=dev)
     check(lib.sd_mbd_external_counts(Xd.data_ptr(), T, n, Qd.data_ptr(), m, J, out.data_ptr(), ws.data_ptr(), wsb,
                                      _stream_ptr(dev)))

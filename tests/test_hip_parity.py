@@ -141,6 +141,30 @@ def test_external_counts_vs_oracle(eng, oracle):
             assert (got[q] == want).all()
 
 
+@pytest.mark.parametrize("n,m", [(40, 20), (700, 33), (5000, 1500), (10000, 2500), (16384, 9000), (20000, 40)])
+def test_external_counts_rows_and_sizes(eng, oracle, monkeypatch, n, m):
+    """External targets through the per-row bucket structure (n <= 16384, m >= 16) and the pairwise kernel (otherwise):
+    rows of every kind, targets inside / outside the set's range, tied with set values, NaN; several target groups."""
+    rng = np.random.default_rng(n + m)
+    T = 12
+    F = rng.normal(size=(T, n)).cumsum(axis=0)
+    G = rng.normal(size=(T, m)).cumsum(axis=0) * 1.5
+    F[1] = np.round(F[1], 0); G[1] = np.round(G[1], 0)          # ties with set values, crowded buckets
+    F[2, ::7] = np.nan; G[2, ::5] = np.nan
+    F[3, 1] = np.inf; F[3, 2] = -np.inf; G[3, 0] = np.inf; G[3, 1] = -np.inf
+    F[4, :] = 0.5; G[4, :3] = [0.5, 0.25, 0.75]                  # all set values equal: target tied / below / above
+    F[5, :] = np.nan
+    G[6, :] = np.nan
+    G[7, :4] = [F[7].min() - 1.0, F[7].max() + 1.0, F[7].min(), F[7].max()]
+    F[8, 1:] = np.nan                                            # a single value in the set
+    tg = np.unique(np.concatenate([np.arange(min(m, 6)), rng.integers(0, m, size=6), [m - 1]]))
+    for J in (2, 3):
+        got = eng.mbd_external_counts(F, G, J=J)
+        for q in tg:
+            Fg = np.concatenate([F, G[:, q:q + 1]], axis=1)
+            assert (got[q] == oracle.mbd_counts(Fg, [n], J)[0]).all(), (q, J)
+
+
 # ---------------------------------------------------------------- randomised, against the oracle
 def _cases():
     rng = np.random.default_rng(123)

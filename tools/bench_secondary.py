@@ -99,7 +99,7 @@ def main():
     F = rng.normal(size=(1000, 10000)).cumsum(axis=0)
     G = rng.normal(size=(1000, 2000)).cumsum(axis=0)
     t = tm(lambda: engine.mbd_external_counts(F, G), 1)
-    emit(kernel="K1+K2 external targets (pairwise)", workload="2000 external curves vs 10000 curves x 1000 timepoints (incl. H2D)",
+    emit(kernel="K1+K2 external targets (bucket look-up)", workload="2000 external curves vs 10000 curves x 1000 timepoints (incl. H2D)",
          seconds=t, unit="curve-pairs/s", value=2000 * 10000 / t)
 
 
