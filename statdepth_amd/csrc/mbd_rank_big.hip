@@ -165,14 +165,14 @@ static inline int bucket_count(i64 n) {
     return (int)nb;
 }
 
-// S: grid = rows; spl[r][0..NB-2] ascending.  SNT threads sort a strided sample of 16 SNT values: 4 096 for up to 72
-// value buckets, 16 384 above (a bucket's fill scatters with 1 / sqrt(samples per bucket); at n = 10^6 the small
+// S: grid = rows; spl[r][0..NB-2] ascending.  SNT threads sort a strided sample of SE SNT values: 2 048 for up to 24
+// value buckets, 4 096 up to 72, 16 384 above (a bucket's fill scatters with 1 / sqrt(samples per bucket); at n = 10^6 the small
 // sample overflowed the 8 192-key buckets and sent every row to the chunked route).
-template <int SNT>
+template <int SNT, int SE>
 __global__ __launch_bounds__(SNT) void bucket_splitters_kernel(const double *__restrict__ Y, i64 n, i64 row0, int NB,
                                                                double *__restrict__ spl) {
-    using Cfg = R2Cfg<SNT, 16>;
-    constexpr int E = 16, LE = Cfg::LE, SS = SNT * 16;
+    using Cfg = R2Cfg<SNT, SE>;
+    constexpr int E = SE, LE = Cfg::LE, SS = SNT * SE;
     extern __shared__ double Sm[];
     const int t = threadIdx.x;
     const i64 rb = blockIdx.x;
@@ -185,7 +185,7 @@ __global__ __launch_bounds__(SNT) void bucket_splitters_kernel(const double *__r
         double v = row[(s * n) / SS];
         k[e] = (v == v) ? v : INF;
     }
-    R2Sorter<SNT, 16>::sort(k, Sm, t, SS, true, INF);
+    R2Sorter<SNT, SE>::sort(k, Sm, t, SS, true, INF);
     double *Sw = Sm + r2_base<0, LE>(t);
 #pragma unroll
     for (int e = 0; e < E; ++e) Sw[r2_off<0, LE>(e)] = k[e];
@@ -867,9 +867,15 @@ int launch_mbd_rank_big(const double *Y, i64 T, i64 n, const i64 *targets, i64 t
     }
     auto k_cs = chunk_sort_kernel;
     auto k_cq = chunk_search_kernel;
-    auto k_sp = bucket_splitters_kernel<256>;
-    auto k_sp_big = bucket_splitters_kernel<1024>;
-    constexpr size_t lds_sp = R2Cfg<256, 16>::LDS_BYTES, lds_sp_big = R2Cfg<1024, 16>::LDS_BYTES;
+    // sample per row: 2 048 values up to 24 value buckets (>= 85 samples per bucket), 4 096 up to 72, 16 384 above.
+    // The sort of the sample by ONE workgroup is pure latency in front of the partition (4 096 keys: 33 us, as 256 x 16
+    // or 1024 x 4 alike), so the sample is no larger than the buckets' capacity margin needs.
+    auto k_sp_small = bucket_splitters_kernel<128, 16>;
+    auto k_sp = bucket_splitters_kernel<256, 16>;
+    auto k_sp_big = bucket_splitters_kernel<1024, 16>;
+    constexpr size_t lds_sp_small = R2Cfg<128, 16>::LDS_BYTES, lds_sp = R2Cfg<256, 16>::LDS_BYTES;
+    constexpr size_t lds_sp_big = R2Cfg<1024, 16>::LDS_BYTES;
+    SD_HIP(hipFuncSetAttribute((const void *)k_sp_small, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sp_small));
     auto k_bp = bucket_packed_kernel;
     auto k_br = bucket_rank_kernel;
     const char *envA = getenv("SD_BIG_SORT");                 // 1: packed-key sort per value bucket (predecessor, cross-check)
@@ -893,7 +899,9 @@ int launch_mbd_rank_big(const double *Y, i64 T, i64 n, const i64 *targets, i64 t
         const u32 *fallback_rows = nullptr;                  // chunked route: every row
         const u32 *nn_for_fold = nanf;
         if (buckets) {
-            if (NB <= 72)
+            if (NB <= 24)
+                hipLaunchKernelGGL(k_sp_small, dim3((unsigned)rows), dim3(128), lds_sp_small, s, Y, n, row0, NB, spl);
+            else if (NB <= 72)
                 hipLaunchKernelGGL(k_sp, dim3((unsigned)rows), dim3(256), lds_sp, s, Y, n, row0, NB, spl);
             else
                 hipLaunchKernelGGL(k_sp_big, dim3((unsigned)rows), dim3(1024), lds_sp_big, s, Y, n, row0, NB, spl);
