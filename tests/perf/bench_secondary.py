@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Throughput of the secondary kernels of the path (K3 strict depth, K4 simplex, K5 L1, chunked K1+K2,
 external targets), each next to the CPU oracle timed on a stated sample.  One JSON object per line.
-Run on the GPU box: python tools/bench_secondary.py > gpurun_out/secondary.jsonl
+Run on the GPU box: python tests/perf/bench_secondary.py > gpurun_out/secondary.jsonl
 """
 import json
 import math
@@ -11,7 +11,7 @@ import time
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch  # noqa: E402
 
 import oracle  # noqa: E402
