@@ -53,7 +53,7 @@ def main():
     ap.add_argument("--J", type=int, default=2)
     ap.add_argument("--algo", default="auto", choices=["auto", "pairwise", "rank"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-targets", type=int, default=4096)
+    ap.add_argument("--cpu-targets", type=int, default=10000)
     ap.add_argument("--variant", default="walk", choices=["walk", "ties"],
                     help="walk: continuous random walks (headline); ties: the same rounded to 1 decimal with 1 %% "
                          "duplicated curves (SURVEY.md 8(d) config 2 variant)")
