@@ -24,6 +24,7 @@
 //      of the pair-image rows the search kernel produced.
 //
 // HBM traffic per call: the matrix once (8 nT) + G partials of 8 n (J-1) bytes written and read once.
+#include <stdio.h>
 #include <stdlib.h>
 
 #include "sd_common.h"
@@ -132,8 +133,8 @@ struct RBCfg {
     }
 };
 
-// DBG (timing experiments only, results invalid): 1 = stop after the range, 2 = after the histogram, 3 = after the
-// prefix sum, 4 = after the scatter
+// DBG (timing experiments only; 1-4: results invalid): 1 = stop after the range, 2 = after the histogram, 3 = after the
+// prefix sum, 4 = after the scatter; 5 = full kernel with cycle stamps per phase printed by wave 0 of workgroup 0
 template <int NT, int E, int LNB, int J, int CAP, int U2, int DBG = 0>
 __global__ __launch_bounds__(NT, RB_WAVES_PER_EU(E)) void rank_bucket_kernel(const double *__restrict__ Y, i64 n64, i64 row0, i64 rows,
                                                          u64 *__restrict__ partial, int p32) {
@@ -199,11 +200,20 @@ __global__ __launch_bounds__(NT, RB_WAVES_PER_EU(E)) void rank_bucket_kernel(con
         double *rp = red + parity * 2 * NW;
         if ((t & 63) == 63) { rp[2 * (t >> 6)] = mn; rp[2 * (t >> 6) + 1] = mx; }
     };
+    long long stamp[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0;        // DBG == 5: cycles per phase, thread 0 of workgroup 0
+    auto mark = [&](int ph) {
+        if constexpr (DBG == 5) {
+            const long long now = (long long)__builtin_readcyclecounter();
+            stamp[ph] += now - tlast;
+            tlast = now;
+        }
+    };
     int par = 0;
     if ((i64)blockIdx.x < rows) {
         load_row(blockIdx.x);
         row_range(0);
     }
+    if constexpr (DBG == 5) tlast = (long long)__builtin_readcyclecounter();
     for (i64 r = blockIdx.x; r < rows; r += gridDim.x) {
         const i64 rnext = r + gridDim.x;
         // Per-row opaque copy of the thread id: every address below derives from it, so the compiler recomputes
@@ -215,7 +225,9 @@ __global__ __launch_bounds__(NT, RB_WAVES_PER_EU(E)) void rank_bucket_kernel(con
         const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
         double *redp = red + par * 2 * NW;
         par ^= 1;
+        mark(0);
         __syncthreads();                                              // barrier 1 (histogram is zero, S is free)
+        mark(1);
         double lo, hi;
         {
             const double2 p = reinterpret_cast<const double2 *>(redp)[lane & 15];
@@ -244,6 +256,7 @@ __global__ __launch_bounds__(NT, RB_WAVES_PER_EU(E)) void rank_bucket_kernel(con
                 const u32 old = atomicAdd(&H[b >> 1], 1u << sh);
                 bs[e] = b | (((old >> sh) & 0xFFFFu) << 16);
             }
+            mark(2);
             __syncthreads();                                          // barrier 2
             uint4 *Hq = reinterpret_cast<uint4 *>(H) + wave * (64 * QW);   // this wave's 64*QW quads, quad i*64+lane
             if constexpr (DBG == 2) {
@@ -269,6 +282,7 @@ __global__ __launch_bounds__(NT, RB_WAVES_PER_EU(E)) void rank_bucket_kernel(con
                 }
                 const bool wover = __ballot((ov & 0x80008000u) != 0) != 0;
                 if (lane == 63) wtot[wave] = wsum | (wover ? 0x80000000u : 0u);
+                mark(3);
                 __syncthreads();                                      // barrier 3
                 const u32 wt = wtot[lane & 15];
                 const bool anyover = __ballot((wt >> 31) != 0) != 0;
@@ -312,6 +326,7 @@ __global__ __launch_bounds__(NT, RB_WAVES_PER_EU(E)) void rank_bucket_kernel(con
         ++rowidx;
         u32 bc[E];                                                    // base | count << 16 | slot << 24; count 0: a NaN
         if (go) {
+            mark(4);
             __syncthreads();                                          // barrier 4
             // ---- (3) scatter into bucket order (branch-free; NaNs write the dummy slot) ----
             const u32 nv = H[NB / 2];
@@ -337,7 +352,9 @@ __global__ __launch_bounds__(NT, RB_WAVES_PER_EU(E)) void rank_bucket_kernel(con
             go = false;
         }
         if (go) {
+            mark(5);
             __syncthreads();                                          // barrier 5
+            mark(6);
             // the histogram is dead until the next row's atomics (behind its barrier 1)
             {
                 uint4 *Hq = reinterpret_cast<uint4 *>(H) + wave * (64 * QW);
@@ -414,8 +431,14 @@ __global__ __launch_bounds__(NT, RB_WAVES_PER_EU(E)) void rank_bucket_kernel(con
             }
         }
         if (rnext < rows) row_range(par);                             // the next row's keys have landed by now
+        mark(7);
     }
     t = t0;
+    if constexpr (DBG == 5) {   // in-kernel stamps (cdna_hip_programming.md, 7): where one wave's cycles go, barrier waits included
+        if (blockIdx.x == 0 && t0 == 0)
+            printf("rb stamps (cycles, wave 0 of workgroup 0): to-b1 %lld | b1-wait %lld | phase1 %lld | b2+prefixA %lld | b3+prefixB %lld | b4+scatter %lld | b5-wait %lld | members+fold+range %lld\n",
+                   stamp[0], stamp[1], stamp[2], stamp[3], stamp[4], stamp[5], stamp[6], stamp[7]);
+    }
     // ---- this workgroup's partial totals (u32 when the host found that they fit: J = 2, few rows per workgroup) ----
     u64 *P = partial + (size_t)blockIdx.x * (J - 1) * n;
     u32 *P32 = reinterpret_cast<u32 *>(partial) + (size_t)blockIdx.x * n;
@@ -739,6 +762,7 @@ static int launch_bucket_cfg(const double *Y, i64 n, i64 row0, i64 rows, u64 *pa
                 case 2: kf = rank_bucket_kernel<NT, E, LNB, J, RB_CAP, U2, 2>; break;
                 case 3: kf = rank_bucket_kernel<NT, E, LNB, J, RB_CAP, U2, 3>; break;
                 case 4: kf = rank_bucket_kernel<NT, E, LNB, J, RB_CAP, U2, 4>; break;
+                case 5: kf = rank_bucket_kernel<NT, E, LNB, J, RB_CAP, U2, 5>; break;
             }
         }
     }
