@@ -395,6 +395,7 @@ bool mbd_rank_bucket_supported(i64 T, i64 n, int J);
 size_t mbd_rank_bucket_workspace_bytes(i64 rows, i64 n, int J);
 int launch_rank_bucket(const double *Y, i64 n, i64 row0, i64 rows, int J, u64 *partial, int *p32_out, int *G_out,
                        hipStream_t s);
+int launch_rank_bucket_image(const double *Y, i64 n, i64 row0, i64 rows, u32 *AB, u32 *nnan, hipStream_t s);
 int launch_rank_finalize(const u64 *partial, int G, int p32, const u32 *AB, const u32 *nnan, const unsigned char *rowflag,
                          i64 rows, i64 n, const i64 *targets, i64 tbegin, i64 m, int J, u64 *out, int first,
                          hipStream_t s);
@@ -455,7 +456,7 @@ int launch_mbd_rank(const double *Y, i64 T, i64 n, const i64 *targets, i64 tbegi
     // 2 = search kernel for every row, 1 = first-generation kernel
     const char *env = getenv("SD_RANK_IMPL");
     int impl = env ? atoi(env) : 4;
-    if (impl == 4 && !mbd_rank_bucket_supported(T, n, J)) impl = 3;
+    if (impl == 4 && !mbd_rank_bucket_supported(T, n, J)) impl = (J >= 4) ? 5 : 3;   // 5: bucket kernel -> pair image -> fold
     if (impl == 1 && J <= 3) return launch_mbd_rank_v1(Y, T, n, targets, tbegin, m, J, out, ws, ws_bytes, s);
     const i64 rpb = ab_rows_per_batch(T, n);
     Carver cv(ws, ws_bytes);
@@ -478,6 +479,7 @@ int launch_mbd_rank(const double *Y, i64 T, i64 n, const i64 *targets, i64 tbegi
         // E = 16 keys per thread throughout; smaller rows take smaller workgroups so that several rows are in
         // flight per CU (n = 4000: 4 workgroups of 256 threads per CU, 0.053 ms against 0.091 ms for 1024 x 4)
         if (impl == 4) rc = SD_OK;
+        else if (impl == 5) rc = launch_rank_bucket_image(Y, n, row0, rows, AB, nnan, s);
         else if (n <= 1024) rc = launch_sorts<64, 16>(Y, n, row0, rows, AB, nnan, impl, s);
         else if (n <= 2048) rc = launch_sorts<128, 16>(Y, n, row0, rows, AB, nnan, impl, s);
         else if (n <= 4096) rc = launch_sorts<256, 16>(Y, n, row0, rows, AB, nnan, impl, s);

@@ -137,12 +137,15 @@ struct RBCfg {
 // prefix sum, 4 = after the scatter; 5 = full kernel with cycle stamps per phase printed by wave 0 of workgroup 0
 template <int NT, int E, int LNB, int J, int CAP, int U2, int DBG = 0>
 __global__ __launch_bounds__(NT, RB_WAVES_PER_EU(E)) void rank_bucket_kernel(const double *__restrict__ Y, i64 n64, i64 row0, i64 rows,
-                                                         u64 *__restrict__ partial, int p32) {
+                                                         u64 *__restrict__ partial, int p32, u32 *__restrict__ nnan_img) {
+    // J == 0: image mode (J >= 4 on the host side): no fold, the pairs (B | A << 16) of every (row, curve) go to the
+    // pair image `partial` (as u32[rows][n]) and the rows' NaN counts to nnan_img; rank_accumulate*_kernel folds them
     using C = RBCfg<NT, E, LNB, U2>;
     constexpr int NB = C::NB, NW = C::NW, QW = C::QW;
     static_assert(2 * U2 - 1 <= RB_PAD, "the first member pass reads at most RB_PAD keys past the end");
     static_assert(CAP < 255 && NB <= 32768, "packing of (base, count, slot)");
-    constexpr int NACC = (J == 2) ? 1 : (J - 1);
+    constexpr int NACC = (J == 2 || J == 0) ? 1 : (J - 1);
+    u32 *ABimg = reinterpret_cast<u32 *>(partial);
     extern __shared__ double Sm[];
     const int n = (int)n64;
     double *red = Sm;                                                 // [2][NW][2] min/max partials
@@ -415,7 +418,9 @@ __global__ __launch_bounds__(NT, RB_WAVES_PER_EU(E)) void rank_bucket_kernel(con
             for (int e = 0; e < E; ++e) {
                 const u32 base = bc[e] & 0xFFFFu, cnt = (bc[e] >> 16) & 0xFFu;
                 const u32 B = base + (pk[e] & 0xFFFFu), A = nv - base - (pk[e] >> 16);
-                if constexpr (J == 2) {
+                if constexpr (J == 0) {
+                    if (e < E - 1 || t + (E - 1) * NT < n) ABimg[r * n + t + e * NT] = cnt ? (B | (A << 16)) : RB_AB_SPECIAL;
+                } else if constexpr (J == 2) {
                     // 2 * contained_2 = 2 N (v - A - B) + v(v-1) - A(A-1) - B(B-1)   (all terms < 2^30)
                     u32 q = __umul24(A, A - 1u) + __umul24(B, B - 1u);   // A, B < 2^15: 24-bit multiplies are exact
                     if (nn) q += 2u * __umul24(nn, A + B);
@@ -423,12 +428,15 @@ __global__ __launch_bounds__(NT, RB_WAVES_PER_EU(E)) void rank_bucket_kernel(con
                 } else {
                     if (cnt) {
                         u64 a7[JMAX - 1] = {0, 0, 0, 0, 0, 0, 0};
-                        band_counts_add<J>(A, B, nn, (u64)(n - 1), a7);
+                        band_counts_add<(J > 0 ? J : 2)>(A, B, nn, (u64)(n - 1), a7);
 #pragma unroll
                         for (int j = 0; j < J - 1; ++j) acc[e][j] += a7[j];
                     }
                 }
             }
+        }
+        if constexpr (J == 0) {
+            if (go && t == 0) nnan_img[r] = nn;
         }
         if (rnext < rows) row_range(par);                             // the next row's keys have landed by now
         mark(7);
@@ -440,11 +448,11 @@ __global__ __launch_bounds__(NT, RB_WAVES_PER_EU(E)) void rank_bucket_kernel(con
                    stamp[0], stamp[1], stamp[2], stamp[3], stamp[4], stamp[5], stamp[6], stamp[7]);
     }
     // ---- this workgroup's partial totals (u32 when the host found that they fit: J = 2, few rows per workgroup) ----
-    u64 *P = partial + (size_t)blockIdx.x * (J - 1) * n;
+    u64 *P = partial + (size_t)blockIdx.x * (J > 0 ? J - 1 : 0) * n;
     u32 *P32 = reinterpret_cast<u32 *>(partial) + (size_t)blockIdx.x * n;
 #pragma unroll
     for (int e = 0; e < E; ++e)
-        if (e < E - 1 || t + (E - 1) * NT < n) {
+        if ((J > 0) && (e < E - 1 || t + (E - 1) * NT < n)) {
             if constexpr (J == 2) {
                 if (p32) P32[t + e * NT] = (u32)(acc[e][0] >> 1);
                 else P[t + e * NT] = acc[e][0] >> 1;
@@ -466,9 +474,12 @@ __global__ __launch_bounds__(NT, RB_WAVES_PER_EU(E)) void rank_bucket_kernel(con
             rb_slow_row(Y + (row0 + r) * n, n, IMG, wtot, ab, &nnan_s);
 #pragma unroll 1
             for (int e = 0; e < RB_SE; ++e) {
-                if (ab[e] != RB_AB_SPECIAL) {                         // implies t + e * NT < n
+                if constexpr (J == 0) {
+                    if (t + e * NT < n) ABimg[r * n + t + e * NT] = ab[e];
+                    if (e == 0 && t == 0) nnan_img[r] = nnan_s;
+                } else if (ab[e] != RB_AB_SPECIAL) {                         // implies t + e * NT < n
                     u64 a7[JMAX - 1] = {0, 0, 0, 0, 0, 0, 0};
-                    band_counts_add<J>(ab[e] >> 16, ab[e] & 0xFFFFu, nnan_s, (u64)(n - 1), a7);
+                    band_counts_add<(J > 0 ? J : 2)>(ab[e] >> 16, ab[e] & 0xFFFFu, nnan_s, (u64)(n - 1), a7);
                     if (J == 2 && p32) P32[t + e * NT] += (u32)a7[0];
                     else {
 #pragma unroll
@@ -752,7 +763,8 @@ size_t mbd_rank_bucket_workspace_bytes(i64 rows, i64 n, int J) {
 #define RB_CAP 80
 #endif
 template <int NT, int E, int LNB, int J, int U2>
-static int launch_bucket_cfg(const double *Y, i64 n, i64 row0, i64 rows, u64 *partial, int p32, int G, hipStream_t s) {
+static int launch_bucket_cfg(const double *Y, i64 n, i64 row0, i64 rows, u64 *partial, int p32, int G, hipStream_t s,
+                             u32 *nnan_img = nullptr) {
     using C = RBCfg<NT, E, LNB, U2>;
     auto kf = rank_bucket_kernel<NT, E, LNB, J, RB_CAP, U2>;
     if constexpr (E == 10 && J == 2 && LNB == 14 && U2 == 3) {
@@ -769,7 +781,7 @@ static int launch_bucket_cfg(const double *Y, i64 n, i64 row0, i64 rows, u64 *pa
     const size_t lds = C::lds_bytes((int)n);
     if (lds > 163840) return fail(SD_ERR_UNSUPPORTED, "bucket kernel: %zu bytes of LDS for n=%lld", lds, (long long)n);
     SD_HIP(hipFuncSetAttribute((const void *)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kf, dim3(G), dim3(NT), lds, s, Y, n, row0, rows, partial, p32);
+    hipLaunchKernelGGL(kf, dim3(G), dim3(NT), lds, s, Y, n, row0, rows, partial, p32, nnan_img);
     SD_HIP(hipGetLastError());
     return SD_OK;
 }
@@ -809,6 +821,21 @@ static int launch_bucket_j(const double *Y, i64 n, i64 row0, i64 rows, u64 *part
         case 16: return launch_bucket_cfg<1024, 16, 13, J, 3>(RB_ARGS);
     }
 #undef RB_ARGS
+    return fail(SD_ERR_UNSUPPORTED, "bucket kernel covers n <= 16384");
+}
+
+// image mode (J >= 4 on the host side): pairs of every (row, curve) to AB, NaN counts per row to nnan
+int launch_rank_bucket_image(const double *Y, i64 n, i64 row0, i64 rows, u32 *AB, u32 *nnan, hipStream_t s) {
+    const int cus = rb_cus();
+    const int G = (int)(rows < cus ? rows : cus);
+    if (rows > (i64)G * 2048) return fail(SD_ERR_INVALID, "bucket kernel: more than 2048 rows per workgroup in one launch");
+    u64 *img = reinterpret_cast<u64 *>(AB);
+#define RB_IM(E_, L_) case E_: return launch_bucket_cfg<1024, E_, L_, 0, 3>(Y, n, row0, rows, img, 0, G, s, nnan);
+    switch ((int)((n + 1023) / 1024)) {
+        RB_IM(1, 13) RB_IM(2, 13) RB_IM(3, 13) RB_IM(4, 13) RB_IM(5, 14) RB_IM(6, 14) RB_IM(7, 14) RB_IM(8, 14)
+        RB_IM(9, 14) RB_IM(10, 14) RB_IM(11, 14) RB_IM(12, 14) RB_IM(13, 14) RB_IM(14, 14) RB_IM(15, 14) RB_IM(16, 13)
+    }
+#undef RB_IM
     return fail(SD_ERR_UNSUPPORTED, "bucket kernel covers n <= 16384");
 }
 

@@ -225,13 +225,22 @@ def test_mbd_counts_range_vs_oracle(eng, oracle):
             assert (eng.mbd_counts_range(X, lo, m, 2, algo=algo) == want).all()
 
 
-def test_mbd_high_J(eng, oracle):
+def test_mbd_high_J(eng, oracle, monkeypatch):
     rng = np.random.default_rng(5)
     X = rng.integers(0, 9, size=(12, 40)).astype(float)
     X[2, 3] = np.nan
     for J in (4, 5, 8):
         for algo in ("pairwise", "rank"):
             assert (eng.mbd_counts(X, None, J, algo=algo) == oracle.mbd_counts(X, None, J)).all()
+    # J >= 4 on the rank path: bucket kernel in image mode + fold, against the sort-based predecessor and the oracle
+    Y = _bucket_rows(np.random.default_rng(6), 16, 3000)
+    tg = np.arange(0, 3000, 111)
+    for J in (4, 5):
+        got = eng.mbd_counts(Y, None, J, algo="rank")
+        monkeypatch.setenv("SD_RANK_IMPL", "3")
+        assert (got == eng.mbd_counts(Y, None, J, algo="rank")).all()
+        monkeypatch.delenv("SD_RANK_IMPL")
+        assert (got[tg] == oracle.mbd_counts(Y, tg, J)).all()
 
 
 def test_rank_implementations_cross_check(eng, oracle, monkeypatch):
