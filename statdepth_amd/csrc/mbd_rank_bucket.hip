@@ -26,6 +26,7 @@
 // HBM traffic per call: the matrix once (8 nT) + G partials of 8 n (J-1) bytes written and read once.
 #include <stdio.h>
 #include <stdlib.h>
+#include <type_traits>
 
 #include "sd_common.h"
 #include "rank_sort.h"
@@ -42,8 +43,8 @@ constexpr u32 RB_ROW_DEFERRED = 0xFFFFFFFFu;
 #define RB_SMALL_E 0
 #endif
 #define RB_WAVES_PER_EU(E) ((E) <= RB_SMALL_E ? 8 : 4)
-#ifndef RB_INFLIGHT
-#define RB_INFLIGHT 2
+#ifndef RB_REDIRECT
+#define RB_REDIRECT 1
 #endif
 constexpr int RB_PAD = 8;                      // NaN sentinels behind the bucket-ordered keys (never < or <= anything)
 
@@ -135,7 +136,7 @@ struct RBCfg {
 
 // DBG (timing experiments only; 1-4: results invalid): 1 = stop after the range, 2 = after the histogram, 3 = after the
 // prefix sum, 4 = after the scatter; 5 = full kernel with cycle stamps per phase printed by wave 0 of workgroup 0
-template <int NT, int E, int LNB, int J, int CAP, int U2, int DBG = 0>
+template <int NT, int E, int LNB, int J, int CAP, int U2, int DBG = 0, bool A32 = false>
 __global__ __launch_bounds__(NT, RB_WAVES_PER_EU(E)) void rank_bucket_kernel(const double *__restrict__ Y, i64 n64, i64 row0, i64 rows,
                                                          u64 *__restrict__ partial, int p32, u32 *__restrict__ nnan_img) {
     // J == 0: image mode (J >= 4 on the host side): no fold, the pairs (B | A << 16) of every (row, curve) go to the
@@ -160,6 +161,7 @@ __global__ __launch_bounds__(NT, RB_WAVES_PER_EU(E)) void rank_bucket_kernel(con
     const double INF = __builtin_huge_val();
     const double QNAN = __builtin_nan("");
     const int DUMMY = C::dummy_pos(n);
+    const double2 *NANP = reinterpret_cast<const double2 *>(S + ((n + 1) & ~1));   // two of the sentinels, 16-byte aligned
     int t = t0;
 
     // LDS setup (once, and again behind rb_slow_row): sentinels + dummy range, empty histogram
@@ -181,8 +183,11 @@ __global__ __launch_bounds__(NT, RB_WAVES_PER_EU(E)) void rank_bucket_kernel(con
 #pragma unroll
         for (int e = 0; e < E; ++e) k[e] = (e < E - 1 || t + (E - 1) * NT < n) ? rp[e * NT] : QNAN;
     };
-    // J == 2: acc[e][0] = 2 * (sum of band counts) (one accumulator, see the fold below); else acc[e][j-2]
-    u64 acc[E][NACC];
+    // J == 2: acc[e][0] = 2 * (sum of band counts) (one accumulator, see the fold below); else acc[e][j-2].
+    // A32 (J == 2, p32 == 2: the host found ceil(rows / G) * n^2 < 2^32): 32-bit accumulators -- E registers fewer
+    static_assert(!A32 || J == 2, "32-bit accumulators: J == 2 only");
+    using ACC = std::conditional_t<A32, u32, u64>;
+    ACC acc[E][NACC];
 #pragma unroll
     for (int e = 0; e < E; ++e)
 #pragma unroll
@@ -378,7 +383,13 @@ __global__ __launch_bounds__(NT, RB_WAVES_PER_EU(E)) void rank_bucket_kernel(con
                 u32 less = 0, le = 0;
 #pragma unroll
                 for (int u = 0; u < U2; ++u) {
+                    // a lane whose bucket ends before this pair reads the NaN pair behind the keys instead: same
+                    // counts (NaN compares false), and lanes sharing one address cost no bank-conflict cycles
+#if RB_REDIRECT
+                    const double2 y = *((u == 0 || cnt + odd > (u32)(2 * u)) ? Sq + u : NANP);
+#else
                     const double2 y = Sq[u];
+#endif
                     less += (y.x < x) ? 1u : 0u;
                     le += (y.x <= x) ? 1u : 0u;
                     less += (y.y < x) ? 1u : 0u;
@@ -387,7 +398,7 @@ __global__ __launch_bounds__(NT, RB_WAVES_PER_EU(E)) void rank_bucket_kernel(con
                 pk[e] = (less - odd) | ((le - odd) << 16);
                 more |= cnt + odd > (u32)(2 * U2);
             }
-            if (__ballot(more) != 0) {
+            if (__ballot(more && !(DBG == 6 && n > 0)) != 0) {   // DBG 6: never taken, code kept (timing experiment)
 #pragma unroll
                 for (int e = 0; e < E; ++e) {
                     u32 bce = bc[e];
@@ -424,7 +435,7 @@ __global__ __launch_bounds__(NT, RB_WAVES_PER_EU(E)) void rank_bucket_kernel(con
                     // 2 * contained_2 = 2 N (v - A - B) + v(v-1) - A(A-1) - B(B-1)   (all terms < 2^30)
                     u32 q = __umul24(A, A - 1u) + __umul24(B, B - 1u);   // A, B < 2^15: 24-bit multiplies are exact
                     if (nn) q += 2u * __umul24(nn, A + B);
-                    acc[e][0] += (u64)(cnt ? R2 - q : 0u);
+                    acc[e][0] += (ACC)(cnt ? R2 - q : 0u);
                 } else {
                     if (cnt) {
                         u64 a7[JMAX - 1] = {0, 0, 0, 0, 0, 0, 0};
@@ -767,6 +778,9 @@ static int launch_bucket_cfg(const double *Y, i64 n, i64 row0, i64 rows, u64 *pa
                              u32 *nnan_img = nullptr) {
     using C = RBCfg<NT, E, LNB, U2>;
     auto kf = rank_bucket_kernel<NT, E, LNB, J, RB_CAP, U2>;
+    if constexpr (J == 2) {
+        if (p32 == 2) kf = rank_bucket_kernel<NT, E, LNB, J, RB_CAP, U2, 0, true>;
+    }
     if constexpr (E == 10 && J == 2 && LNB == 14 && U2 == 3) {
         if (const char *d = getenv("SD_RB_DBG")) {        // timing experiments: truncated kernels
             switch (atoi(d)) {
@@ -775,6 +789,7 @@ static int launch_bucket_cfg(const double *Y, i64 n, i64 row0, i64 rows, u64 *pa
                 case 3: kf = rank_bucket_kernel<NT, E, LNB, J, RB_CAP, U2, 3>; break;
                 case 4: kf = rank_bucket_kernel<NT, E, LNB, J, RB_CAP, U2, 4>; break;
                 case 5: kf = rank_bucket_kernel<NT, E, LNB, J, RB_CAP, U2, 5>; break;
+                case 6: kf = rank_bucket_kernel<NT, E, LNB, J, RB_CAP, U2, 6>; break;
             }
         }
     }
@@ -849,7 +864,9 @@ int launch_rank_bucket(const double *Y, i64 n, i64 row0, i64 rows, int J, u64 *p
     if (rows > (i64)G * 2048) return fail(SD_ERR_INVALID, "bucket kernel: more than 2048 rows per workgroup in one launch");
     // J = 2: a workgroup's total is at most ceil(rows / G) * C(n-1, 2); below 2^32 the partials travel as u32
     const u64 per_wg = (u64)((rows + G - 1) / G) * ((u64)(n - 1) * (u64)(n - 2) / 2);
-    const int p32 = (J == 2 && per_wg < ((u64)1 << 32)) ? 1 : 0;
+    int p32 = (J == 2 && per_wg < ((u64)1 << 32)) ? 1 : 0;
+    // ... and 2 * total stays below 2^32 too (2 * C(v,2) + 2 N v < n^2 per row): the kernel accumulates in 32 bits
+    if (p32 && (u64)((rows + G - 1) / G) * (u64)n * (u64)n < ((u64)1 << 32) && !getenv("SD_RB_ACC64")) p32 = 2;
     *p32_out = p32;
     if (J == 2) return launch_bucket_j<2>(Y, n, row0, rows, partial, p32, G, s);
     if (J == 3) return launch_bucket_j<3>(Y, n, row0, rows, partial, p32, G, s);

@@ -314,6 +314,23 @@ def test_bucket_kernel_many_rows_per_workgroup(eng, oracle):
     assert (eng.mbd_counts(X, None, 2, algo="rank")[tg] == oracle.mbd_counts(X, tg, 2)).all()
 
 
+@pytest.mark.parametrize("T", [2100, 4100, 8200])
+def test_bucket_kernel_accumulator_widths(eng, oracle, T):
+    """n = 16000: 9 rows per workgroup -> 32-bit register accumulators and u32 partial totals; 17 rows -> 64-bit
+    accumulators, u32 partials; 33 rows -> u64 throughout.  The totals near the middle ranks approach
+    rows * C(n-1, 2) / 2, so a width chosen too small would wrap."""
+    rng = np.random.default_rng(T)
+    n = 16000
+    X = rng.normal(size=(T, n))
+    order = np.argsort(X[0])
+    tg = np.concatenate([order[n // 2 - 2:n // 2 + 2], order[:2], order[-2:]])
+    X[:, tg[:4]] *= 1e-3                                  # four curves that stay near the middle: the largest totals
+    want = oracle.mbd_counts(X, tg, 2)
+    got = eng.mbd_counts(X, None, 2, algo="rank")[tg]
+    assert (got == want).all()
+    assert int(want.max()) > T * (n - 1) * (n - 2) // 5
+
+
 def test_above_below_vs_oracle(eng, oracle):
     rng = np.random.default_rng(9)
     X = rng.integers(0, 5, size=(21, 130)).astype(float)
