@@ -46,6 +46,9 @@ constexpr u32 RB_ROW_DEFERRED = 0xFFFFFFFFu;
 #ifndef RB_REDIRECT
 #define RB_REDIRECT 1
 #endif
+#ifndef RB_PIPE
+#define RB_PIPE 0
+#endif
 constexpr int RB_PAD = 8;                      // NaN sentinels behind the bucket-ordered keys (never < or <= anything)
 
 // ---------------------------------------------------------------------------------------------------
@@ -374,29 +377,44 @@ __global__ __launch_bounds__(NT, RB_WAVES_PER_EU(E)) void rank_bucket_kernel(con
             //      bucket, compares below, and is taken off again.  Second pass: the rest of longer buckets. ----
             u32 pk[E];                                                // less | le << 16
             bool more = false;
-#pragma unroll
-            for (int e = 0; e < E; ++e) {
+            // the reads of key e + 1 are issued before the compares of key e (two keys' windows in flight per lane).
+            // A lane whose bucket ends before a pair reads the NaN pair behind the keys instead: same counts (NaN
+            // compares false), and lanes sharing one address cost no bank-conflict cycles.
+            double xw[2];
+            double2 yw[2][U2];
+            auto window = [&](int e, int w) {
                 const u32 base = bc[e] & 0xFFFFu, cnt = (bc[e] >> 16) & 0xFFu, slot = bc[e] >> 24;
                 const u32 odd = base & 1u;
-                const double x = S[base + slot];                      // own key (its registers hold the next row)
+                xw[w] = S[base + slot];                               // own key (its registers hold the next row)
                 const double2 *Sq = reinterpret_cast<const double2 *>(S + (base - odd));
+#pragma unroll
+                for (int u = 0; u < U2; ++u) {
+#if RB_REDIRECT
+                    yw[w][u] = *((u == 0 || cnt + odd > (u32)(2 * u)) ? Sq + u : NANP);
+#else
+                    yw[w][u] = Sq[u];
+#endif
+                }
+            };
+            window(0, 0);
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                if (RB_PIPE && e + 1 < E) window(e + 1, (e + 1) & 1);
+                const int w = RB_PIPE ? (e & 1) : 0;
+                const u32 base = bc[e] & 0xFFFFu, cnt = (bc[e] >> 16) & 0xFFu;
+                const u32 odd = base & 1u;
+                const double x = xw[w];
                 u32 less = 0, le = 0;
 #pragma unroll
                 for (int u = 0; u < U2; ++u) {
-                    // a lane whose bucket ends before this pair reads the NaN pair behind the keys instead: same
-                    // counts (NaN compares false), and lanes sharing one address cost no bank-conflict cycles
-#if RB_REDIRECT
-                    const double2 y = *((u == 0 || cnt + odd > (u32)(2 * u)) ? Sq + u : NANP);
-#else
-                    const double2 y = Sq[u];
-#endif
-                    less += (y.x < x) ? 1u : 0u;
-                    le += (y.x <= x) ? 1u : 0u;
-                    less += (y.y < x) ? 1u : 0u;
-                    le += (y.y <= x) ? 1u : 0u;
+                    less += (yw[w][u].x < x) ? 1u : 0u;
+                    le += (yw[w][u].x <= x) ? 1u : 0u;
+                    less += (yw[w][u].y < x) ? 1u : 0u;
+                    le += (yw[w][u].y <= x) ? 1u : 0u;
                 }
                 pk[e] = (less - odd) | ((le - odd) << 16);
                 more |= cnt + odd > (u32)(2 * U2);
+                if (!RB_PIPE && e + 1 < E) window(e + 1, 0);
             }
             if (__ballot(more && !(DBG == 6 && n > 0)) != 0) {   // DBG 6: never taken, code kept (timing experiment)
 #pragma unroll
@@ -744,6 +762,38 @@ __global__ __launch_bounds__(1024) void rank_finalize_kernel(const u64 *__restri
     }
 }
 
+// Z for the common case (J = 2, u32 partial totals, a contiguous 4-aligned block of targets, no pair image): thread
+// (x, y) of a 256-thread block sums slice y of the G partial blocks for the 4 curves tbegin + 4 (8 blockIdx + x) ..
+// with 16-byte loads; block = 32 curves x 32 slices.
+__global__ __launch_bounds__(256) void rank_finalize4_kernel(const u32 *__restrict__ partial, int G, i64 n, i64 tbegin, i64 m,
+                                                            u64 *__restrict__ out, int first) {
+    __shared__ u64 red[32][8][4 + 1];
+    const int x = threadIdx.x & 7, y = threadIdx.x >> 3;
+    const i64 q = ((i64)blockIdx.x * 8 + x) * 4;                      // first of this thread's 4 targets
+    u64 a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+    if (q < m) {
+        const u32 *p = partial + tbegin + q;
+#pragma unroll 8
+        for (int g = y; g < G; g += 32) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(p + (size_t)g * n);
+            a0 += v.x; a1 += v.y; a2 += v.z; a3 += v.w;
+        }
+    }
+    red[y][x][0] = a0; red[y][x][1] = a1; red[y][x][2] = a2; red[y][x][3] = a3;
+    __syncthreads();
+    if (threadIdx.x < 32) {
+        const int xx = threadIdx.x >> 2, c = threadIdx.x & 3;
+        const i64 qq = ((i64)blockIdx.x * 8 + xx) * 4 + c;
+        if (qq < m) {
+            u64 tot = 0;
+#pragma unroll
+            for (int k = 0; k < 32; ++k) tot += red[k][xx][c];
+            if (first) out[qq] = tot;
+            else out[qq] += tot;
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------
@@ -877,7 +927,10 @@ int launch_rank_finalize(const u64 *partial, int G, int p32, const u32 *AB, cons
                          i64 rows, i64 n, const i64 *targets, i64 tbegin, i64 m, int J, u64 *out, int first,
                          hipStream_t s) {
     dim3 grid((unsigned)((m + 31) / 32));
-    if (J == 2)
+    if (J == 2 && p32 && !targets && !rowflag && n % 4 == 0 && tbegin % 4 == 0 && m % 4 == 0 && !getenv("SD_RB_FINAL1"))
+        hipLaunchKernelGGL(rank_finalize4_kernel, grid, dim3(256), 0, s, reinterpret_cast<const u32 *>(partial), G, n, tbegin, m,
+                           out, first);
+    else if (J == 2)
         hipLaunchKernelGGL((rank_finalize_kernel<2>), grid, dim3(1024), 0, s, partial, G, p32, AB, nnan, rowflag, rows, n, targets,
                            tbegin, m, out, first);
     else

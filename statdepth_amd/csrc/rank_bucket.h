@@ -74,4 +74,5 @@ __device__ __forceinline__ double rb_wave_allreduce(double v) {
     return r;
 }
 
+
 }  // namespace sd
