@@ -46,8 +46,8 @@ def pmc_traffic(kernel, n, T, J):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--n-loc", type=int, default=10000)
     ap.add_argument("--T", type=int, default=1000)
     ap.add_argument("--J", type=int, default=2)
