@@ -17,11 +17,12 @@
 //      are accumulated in REGISTERS across the workgroup's rows; one partial total per (workgroup, curve)
 //      goes to HBM at the end: the matrix is read once and nothing per (row, curve) is ever written.
 //      NaNs stay out of the histogram and weigh in as pandas' skipna does; +-inf take the end buckets.
-//      A row whose finite values are all equal or that has a bucket of more than CAP keys (heavy ties,
-//      clustered data) is left to the sort + search kernel (rank_search_kernel, mbd_rank_ab.hip), which
-//      writes that row of the pair image.
-//   Z  rank_finalize_kernel -- totals of the requested targets = sum of the workgroups' partials + the fold
-//      of the pair-image rows the search kernel produced.
+//      Tie-heavy rows (a bucket of 16 keys or more): when every bucket of the row holds ONE value -- quantised or
+//      integer data, a row of equal values -- the ranks are closed form (less = 0, le = count) and the row needs no
+//      member pass at all.  A row with an infinity, or with a bucket above CAP keys that mixes values, is set aside
+//      and sorted by the same workgroup behind its row loop (rb_slow_row).
+//   Z  rank_finalize_kernel / rank_finalize4_kernel -- totals of the requested targets = sum of the workgroups'
+//      partials (+ the fold of pair-image rows when the caller supplies one).
 //
 // HBM traffic per call: the matrix once (8 nT) + G partials of 8 n (J-1) bytes written and read once.
 #include <stdio.h>
@@ -45,6 +46,9 @@ constexpr u32 RB_ROW_DEFERRED = 0xFFFFFFFFu;
 #define RB_WAVES_PER_EU(E) ((E) <= RB_SMALL_E ? 8 : 4)
 #ifndef RB_REDIRECT
 #define RB_REDIRECT 1
+#endif
+#ifndef RB_TIES
+#define RB_TIES 1
 #endif
 #ifndef RB_PIPE
 #define RB_PIPE 0
@@ -147,7 +151,8 @@ __global__ __launch_bounds__(NT, RB_WAVES_PER_EU(E)) void rank_bucket_kernel(con
     using C = RBCfg<NT, E, LNB, U2>;
     constexpr int NB = C::NB, NW = C::NW, QW = C::QW;
     static_assert(2 * U2 - 1 <= RB_PAD, "the first member pass reads at most RB_PAD keys past the end");
-    static_assert(CAP < 255 && NB <= 32768, "packing of (base, count, slot)");
+    static_assert(CAP == 127 && NB <= 32768, "packing of (base, count, slot); the crowding test reads the counters' bits");
+    constexpr int TRYB = (E == 16) ? 5 : 4;     // buckets of 16 (32 at NB = 8192 / n > 15360) keys: ties rather than density
     constexpr int NACC = (J == 2 || J == 0) ? 1 : (J - 1);
     u32 *ABimg = reinterpret_cast<u32 *>(partial);
     extern __shared__ double Sm[];
@@ -245,14 +250,17 @@ __global__ __launch_bounds__(NT, RB_WAVES_PER_EU(E)) void rank_bucket_kernel(con
             lo = rb_readlane_f64(rb_row_allreduce<false>(p.x), 0);
             hi = rb_readlane_f64(rb_row_allreduce<true>(p.y), 0);
         }
-        const double scale = (double)NB / (hi - lo);                  // range overflow -> 0 -> one crowded bucket
+        // range overflow -> 0 -> one crowded bucket; all values equal -> 0 -> one bucket of one value (closed form below)
+        const double scale = (hi > lo) ? (double)NB / (hi - lo) : 0.0;
         // Every decision below is block-uniform.  The next row is loaded at ONE place (two load sites would
-        // keep two copies of the key registers alive across the loop).  A row with an infinity, with all its
-        // values equal or with none goes to the search kernel.
-        bool go = (hi > lo) && (scale < INF) && (lo > -INF) && (hi < INF);
+        // keep two copies of the key registers alive across the loop).  A row with an infinity or without any
+        // value is set aside for the sort behind the loop.
+        bool go = (hi >= lo) && (scale < INF) && (lo > -INF) && (hi < INF);
         if constexpr (DBG == 1) go = false;
         u32 bs[E];
         u32 nn = 0;                                                   // NaN others of this row (block-uniform)
+        // block-uniform: a bucket above CAP keys / a bucket of 2^TRYB keys or more (ties?  see the member phase)
+        bool crowded = false, trypure = false;
         if (go) {
             // ---- (1) bucket + slot, branch-free.  min(fl(fl(x - lo) * scale), NB-1) is non-decreasing in x;
             //      NaNs count into a dummy word behind the histogram ----
@@ -280,27 +288,27 @@ __global__ __launch_bounds__(NT, RB_WAVES_PER_EU(E)) void rank_bucket_kernel(con
                 //      a crowded bucket defers the row ----
                 uint4 hq[QW];
                 u32 runq[QW], inclq[QW], offq[QW], ov = 0, wsum = 0;
-                constexpr u32 OVK = (u32)(0x7FFF - CAP) * 0x10001u;   // x + OVK: bit 15 / 31 set iff that counter > CAP
 #pragma unroll
                 for (int i = 0; i < QW; ++i) {
                     hq[i] = Hq[i * 64 + lane];
                     const u32 s4 = hq[i].x + hq[i].y + hq[i].z + hq[i].w;   // both halves at once: no half exceeds 16384
-                    ov |= (hq[i].x + OVK) | (hq[i].y + OVK) | (hq[i].z + OVK) | (hq[i].w + OVK);
+                    ov |= hq[i].x | hq[i].y | hq[i].z | hq[i].w;            // bit k of a half set <=> some counter has it
                     runq[i] = (s4 & 0xFFFFu) + (s4 >> 16);
                     inclq[i] = rb_wave_incl_scan(runq[i]);
                     offq[i] = wsum;
                     wsum += rb_readlane(inclq[i], 63);
                 }
-                const bool wover = __ballot((ov & 0x80008000u) != 0) != 0;
-                if (lane == 63) wtot[wave] = wsum | (wover ? 0x80000000u : 0u);
+                // some counter > CAP (= 2^7 - 1) / some counter >= 2^TRYB: any of the bits from there up is set
+                constexpr u32 HIM = (0xFFFFu & ~(u32)CAP) * 0x10001u, TRM = (0xFFFFu & ~((1u << TRYB) - 1u)) * 0x10001u;
+                const bool wover = __ballot((ov & HIM) != 0) != 0, wtry = __ballot((ov & TRM) != 0) != 0;
+                if (lane == 63) wtot[wave] = wsum | (wover ? 0x80000000u : 0u) | (wtry ? 0x40000000u : 0u);
                 mark(3);
                 __syncthreads();                                      // barrier 3
                 const u32 wt = wtot[lane & 15];
-                const bool anyover = __ballot((wt >> 31) != 0) != 0;
-                const u32 wscan = rb_row_incl_scan(wt & 0x7FFFFFFFu);
+                crowded = __ballot((wt >> 31) != 0) != 0;
+                trypure = RB_TIES && __ballot((wt & 0x40000000u) != 0) != 0;
+                const u32 wscan = rb_row_incl_scan(wt & 0x3FFFFFFFu);
                 const u32 woff = wave ? rb_readlane(wscan, wave - 1) : 0u;
-                go = !anyover;
-                // a crowded row leaves zeros behind (the next user is the next row's histogram, behind barrier 1)
 #pragma unroll
                 for (int i = 0; i < QW; ++i) {
                     u32 base = woff + offq[i] + inclq[i] - runq[i];
@@ -313,7 +321,7 @@ __global__ __launch_bounds__(NT, RB_WAVES_PER_EU(E)) void rank_bucket_kernel(con
                     base += (hq[i].z & 0xFFFFu) + (hq[i].z >> 16);
                     o.w = base | ((base + (hq[i].w & 0xFFFFu)) << 16);
                     base += (hq[i].w & 0xFFFFu) + (hq[i].w >> 16);
-                    Hq[i * 64 + lane] = go ? o : make_uint4(0, 0, 0, 0);
+                    Hq[i * 64 + lane] = o;
                     // base past the last bucket = number of non-NaN keys
                     if (i == QW - 1 && t == NT - 1) H[NB / 2] = base;
                 }
@@ -336,19 +344,32 @@ __global__ __launch_bounds__(NT, RB_WAVES_PER_EU(E)) void rank_bucket_kernel(con
         }
         ++rowidx;
         u32 bc[E];                                                    // base | count << 16 | slot << 24; count 0: a NaN
+        u32 (&pk)[E] = bs;                                            // member phase: less | le << 16, in bs's registers
         if (go) {
             mark(4);
             __syncthreads();                                          // barrier 4
             // ---- (3) scatter into bucket order (branch-free; NaNs write the dummy slot) ----
             const u32 nv = H[NB / 2];
             nn = (u32)n - nv;
+            if (!trypure) {
 #pragma unroll
-            for (int e = 0; e < E; ++e) {
-                const u32 b = bs[e] & 0xFFFFu, slot = bs[e] >> 16;
-                const u32 base = H16[b], end = H16[b + 1];
-                const bool isk = b < (u32)NB;
-                S[isk ? base + slot : (u32)DUMMY] = k[e];
-                bc[e] = isk ? (base | ((end - base) << 16) | (slot << 24)) : 0u;
+                for (int e = 0; e < E; ++e) {
+                    const u32 b = bs[e] & 0xFFFFu, slot = bs[e] >> 16;
+                    const u32 base = H16[b], end = H16[b + 1];
+                    const bool isk = b < (u32)NB;
+                    S[isk ? base + slot : (u32)DUMMY] = k[e];
+                    bc[e] = isk ? (base | ((end - base) << 16) | (slot << 24)) : 0u;
+                }
+            } else {                                                  // counts and slots beyond 8 bits: two words
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    const u32 b = bs[e] & 0xFFFFu, slot = bs[e] >> 16;
+                    const u32 base = H16[b], end = H16[b + 1];
+                    const bool isk = b < (u32)NB;
+                    S[isk ? base + slot : (u32)DUMMY] = k[e];
+                    bc[e] = base | (slot << 16);
+                    pk[e] = isk ? end - base : 0u;
+                }
             }
             if (nn && t < RB_PAD) S[nv + t] = QNAN;                   // sentinels behind a row shortened by NaNs
         }
@@ -375,8 +396,42 @@ __global__ __launch_bounds__(NT, RB_WAVES_PER_EU(E)) void rank_bucket_kernel(con
             // ---- (4) rank inside the bucket.  First pass, branch-free: 2*U2 keys from the even position at or
             //      below the bucket's base (16-byte reads); a key in front of an odd base belongs to an earlier
             //      bucket, compares below, and is taken off again.  Second pass: the rest of longer buckets. ----
-            u32 pk[E];                                                // less | le << 16
+            // A row with a bucket of 2^TRYB keys or more is tie-heavy data more often than a dense cluster: if every
+            // bucket of the row holds ONE value (all members equal their bucket's first key), the ranks are closed
+            // form -- less = 0, le = count -- and there is no member pass at all.  Else the row goes the normal way,
+            // or to the sort behind the loop when a bucket is above CAP.
+            int mode = 0;                                             // 0: member passes, 1: closed form, 2: set aside
+            if (trypure) {                                            // block-uniform
+                bool pure = true;
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    const u32 base = bc[e] & 0xFFFFu, slot = bc[e] >> 16;
+                    if (pk[e]) pure = pure && (S[base + slot] == S[base]);
+                }
+                if (__syncthreads_and(pure)) {
+                    mode = 1;
+#pragma unroll
+                    for (int e = 0; e < E; ++e) {
+                        const u32 cnt = pk[e];
+                        bc[e] = (bc[e] & 0xFFFFu) | (cnt ? 0x10000u : 0u);
+                        pk[e] = cnt << 16;
+                    }
+                } else if (crowded) {
+                    mode = 2;
+                    if constexpr (DBG == 0) {
+                        if (t == 0) defer[(rowidx - 1) >> 5] |= 1u << ((rowidx - 1) & 31);
+                        ++ndefer;
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < E; ++e) {
+                        const u32 cnt = pk[e];
+                        bc[e] = cnt ? ((bc[e] & 0xFFFFu) | (cnt << 16) | ((bc[e] >> 16) << 24)) : 0u;
+                    }
+                }
+            }
             bool more = false;
+            if (mode == 0) {
             // the reads of key e + 1 are issued before the compares of key e (two keys' windows in flight per lane).
             // A lane whose bucket ends before a pair reads the NaN pair behind the keys instead: same counts (NaN
             // compares false), and lanes sharing one address cost no bank-conflict cycles.
@@ -439,7 +494,9 @@ __global__ __launch_bounds__(NT, RB_WAVES_PER_EU(E)) void rank_bucket_kernel(con
                     }
                 }
             }
+            }                                                         // mode == 0
             // ---- fold ----
+            if (mode != 2) {
             const u32 nv = (u32)n - nn;                               // non-NaN keys of the row
             const u32 v = nv - 1u;                                    // valid others of a non-NaN target
             const u32 R2 = v * (v - 1u + 2u * nn);                    // J == 2: 2 * [N v + C(v,2)]  (< 2^30)
@@ -463,6 +520,7 @@ __global__ __launch_bounds__(NT, RB_WAVES_PER_EU(E)) void rank_bucket_kernel(con
                     }
                 }
             }
+            }                                                         // mode != 2
         }
         if constexpr (J == 0) {
             if (go && t == 0) nnan_img[r] = nn;
@@ -821,7 +879,7 @@ size_t mbd_rank_bucket_workspace_bytes(i64 rows, i64 n, int J) {
 }
 
 #ifndef RB_CAP
-#define RB_CAP 80
+#define RB_CAP 127
 #endif
 template <int NT, int E, int LNB, int J, int U2>
 static int launch_bucket_cfg(const double *Y, i64 n, i64 row0, i64 rows, u64 *partial, int p32, int G, hipStream_t s,

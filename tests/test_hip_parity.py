@@ -314,6 +314,32 @@ def test_bucket_kernel_many_rows_per_workgroup(eng, oracle):
     assert (eng.mbd_counts(X, None, 2, algo="rank")[tg] == oracle.mbd_counts(X, tg, 2)).all()
 
 
+@pytest.mark.parametrize("n", [700, 3000, 10000, 16384])
+def test_bucket_kernel_tie_rows(eng, oracle, n):
+    """Rows with big buckets: every bucket holds one value (closed form, no member pass), a crowded bucket with two
+    values a hair apart (set aside for the sort), a moderately full mixed bucket (back to the member passes), with
+    and without NaNs; in between ordinary rows."""
+    rng = np.random.default_rng(n)
+    T = 40
+    X = rng.normal(size=(T, n)).cumsum(axis=0)
+    X[0::8] = rng.integers(0, 6, size=X[0::8].shape).astype(float)            # pure, far above CAP keys per bucket
+    X[1::8] = np.round(X[1::8], 1)                                            # pure, moderate buckets
+    r2 = rng.integers(0, 4, size=X[2::8].shape).astype(float)
+    r2[:, : n // 3] = np.where(rng.random((r2.shape[0], n // 3)) < 0.5, 1.0, 1.0 + 1e-13)
+    X[2::8] = r2                                                              # crowded and mixed: the sort
+    r3 = rng.uniform(0, 100, size=X[3::8].shape)
+    r3[:, :40] = np.where(rng.random((r3.shape[0], 40)) < 0.5, 50.0, 50.0 + 1e-12)
+    X[3::8] = r3                                                              # 40 keys, two values, one bucket
+    X[4::8] = X[0::8]
+    X[4::8][rng.random(X[4::8].shape) < 0.1] = np.nan                         # pure with NaNs
+    X[5, :] = 3.0
+    X[5, ::3] = np.nan
+    tg = np.unique(rng.integers(0, n, size=60))
+    for J in (2, 3, 4):
+        got = eng.mbd_counts(X, None, J, algo="rank")[tg]
+        assert (got == oracle.mbd_counts(X, tg, J)).all(), J
+
+
 @pytest.mark.parametrize("T", [2100, 4100, 8200])
 def test_bucket_kernel_accumulator_widths(eng, oracle, T):
     """n = 16000: 9 rows per workgroup -> 32-bit register accumulators and u32 partial totals; 17 rows -> 64-bit
