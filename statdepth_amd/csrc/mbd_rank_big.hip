@@ -484,7 +484,8 @@ __global__ __launch_bounds__(BK_NT) void bucket_packed_kernel(i64 n, int NB, con
 // are < / <= itself: B = (keys in earlier value buckets) + base + less, A = n_real - (... + base + le).  Ties are exact.
 // A value bucket whose keys are all equal is closed-form; one with a fine bucket above BR_CAP keys (heavy ties that
 // are not all equal, an infinity stretching the range) is flagged for bucket_search_kernel like before.
-constexpr int BR_NT = 512, BR_E = 16, BR_LNB = 12, BR_NBF = 1 << BR_LNB, BR_CAP = 40, BR_U2 = 3, BR_PAD = 8;
+constexpr int BR_NT = 512, BR_E = 16, BR_LNB = 12, BR_NBF = 1 << BR_LNB, BR_CAP = 63, BR_TRYB = 4, BR_U2 = 3, BR_PAD = 8;
+static_assert(((BR_CAP + 1) & BR_CAP) == 0, "the crowding test reads the counters' bits");
 constexpr int BR_NW = BR_NT / 64;
 static_assert(BR_NT * BR_E == BK_C, "one thread slot per key of a full value bucket");
 static_assert(BR_NBF / 2 / BR_NT == 4, "one 16-byte quad of histogram words per thread");
@@ -595,24 +596,23 @@ __global__ __launch_bounds__(BR_NT) void bucket_rank_kernel(i64 n, i64 rows, int
         bs[e] = fb | (((old >> sh) & 0xFFFFu) << 16);
     }
     __syncthreads();                                                  // barrier 2
-    // ---- (2) exclusive prefix sum; crowded fine bucket -> the search kernel ----
+    // ---- (2) exclusive prefix sum; a fine bucket of 2^BR_TRYB keys or more: ties?  (checked behind the scatter) ----
+    bool anyover = false, anytry = false;
     {
         const uint4 hq = reinterpret_cast<const uint4 *>(H)[t];
-        constexpr u32 OVK = (u32)(0x7FFF - BR_CAP) * 0x10001u;
+        // some counter > BR_CAP / >= 2^BR_TRYB: bit k of a half-word of the OR is set iff some counter has it
+        constexpr u32 HIM = (0xFFFFu & ~(u32)BR_CAP) * 0x10001u, TRM = (0xFFFFu & ~((1u << BR_TRYB) - 1u)) * 0x10001u;
         const u32 s4 = hq.x + hq.y + hq.z + hq.w;
-        const u32 ov = (hq.x + OVK) | (hq.y + OVK) | (hq.z + OVK) | (hq.w + OVK);
+        const u32 ov = hq.x | hq.y | hq.z | hq.w;
         const u32 run = (s4 & 0xFFFFu) + (s4 >> 16);
         const u32 incl = rb_wave_incl_scan(run);
-        const bool wover = __ballot((ov & 0x80008000u) != 0) != 0;
-        if (lane == 63) wtot[wave] = incl | (wover ? 0x80000000u : 0u);
+        const bool wover = __ballot((ov & HIM) != 0) != 0, wtry = __ballot((ov & TRM) != 0) != 0;
+        if (lane == 63) wtot[wave] = incl | (wover ? 0x80000000u : 0u) | (wtry ? 0x40000000u : 0u);
         __syncthreads();                                              // barrier 3
         const u32 wt = (lane < NW) ? wtot[lane] : 0u;
-        const bool anyover = __ballot((wt >> 31) != 0) != 0;
-        if (anyover) {                                                // block-uniform
-            if (t == 0) bflag[rb * NB + b] = 1u;
-            return;
-        }
-        const u32 wscan = rb_row_incl_scan(wt & 0x7FFFFFFFu);
+        anyover = __ballot((wt >> 31) != 0) != 0;                     // block-uniform
+        anytry = __ballot((wt & 0x40000000u) != 0) != 0;
+        const u32 wscan = rb_row_incl_scan(wt & 0x3FFFFFFFu);
         u32 base = (wave ? rb_readlane(wscan, wave - 1) : 0u) + incl - run;
         uint4 o;
         o.x = base | ((base + (hq.x & 0xFFFFu)) << 16);
@@ -640,6 +640,34 @@ __global__ __launch_bounds__(BR_NT) void bucket_rank_kernel(i64 n, i64 rows, int
         bc[e] = isk ? (base | ((end - base) << 16)) : 0u;
     }
     __syncthreads();                                                  // barrier 5
+    if (anytry) {                                                     // block-uniform
+        // tie-heavy data: when every fine bucket holds ONE value, less = 0 and le = count -- no member pass.
+        // Else: the normal way, or the search kernel when a fine bucket is above BR_CAP keys.
+        bool pure = true;
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            if (e * NT >= cnt) break;
+            if (bc[e] >> 16) pure = pure && (S[bc[e] & 0xFFFFu] == k[e]);
+        }
+        if (__syncthreads_and(pure)) {
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                if (e * NT >= cnt) break;
+                const u32 base = bc[e] & 0xFFFFu, fc = bc[e] >> 16;
+                if (fc) {
+                    AB2 v;
+                    v.B = gbase + base;
+                    v.A = nreal - (gbase + base + fc);
+                    abrow[idp[e * NT]] = v;
+                }
+            }
+            return;
+        }
+        if (anyover) {
+            if (t == 0) bflag[rb * NB + b] = 1u;
+            return;
+        }
+    }
     // ---- (4) rank inside the fine bucket (the keys are still in registers), write the pairs ----
 #pragma unroll
     for (int e = 0; e < E; ++e) {

@@ -585,6 +585,24 @@ def test_row_batching(eng, oracle, monkeypatch):
     assert (eng.mbd_counts(Xb, None, 2, algo="rank") == oracle.mbd_counts(Xb, None, 2)).all()
 
 
+
+def test_big_n_tie_rows(eng, oracle):
+    """n > 16384, tie-heavy rows inside the value buckets: one value per fine bucket (closed form), a crowded fine
+    bucket mixing two values a hair apart (search kernel), a moderately full mixed fine bucket (member passes)."""
+    rng = np.random.default_rng(99)
+    T, n = 6, 40000
+    X = rng.normal(size=(T, n)).cumsum(axis=0)
+    X[0] = np.round(X[0] * 10, 0)                                  # ~100 distinct values
+    X[1] = rng.integers(0, 1000, size=n).astype(float)
+    X[2, : n // 2] = np.where(rng.random(n // 2) < 0.5, 1.0, 1.0 + 1e-13)
+    X[3, :40] = np.where(rng.random(40) < 0.5, 0.5, 0.5 + 1e-14)
+    X[4] = np.round(X[4], 1)
+    X[4, ::9] = np.nan
+    tg = np.unique(rng.integers(0, n, size=50))
+    for J in (2, 3):
+        assert (eng.mbd_counts(X, None, J, algo="rank")[tg] == oracle.mbd_counts(X, tg, J)).all(), J
+
+
 def test_big_n_routes(eng, oracle, monkeypatch):
     """n > 16384: value-bucket route (default), its overflow fallback (a row where most values tie cannot be cut
     into buckets of 8192) and the chunked route forced for every row: identical integers."""
