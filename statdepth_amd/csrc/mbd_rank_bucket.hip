@@ -337,9 +337,19 @@ __global__ __launch_bounds__(NT, RB_WAVES_PER_EU(E)) void rank_bucket_kernel(con
             go = false;
         }
         if constexpr (DBG == 0) {
-            if (!go) {                                                // set aside: sorted behind the loop
-                if (t == 0) defer[rowidx >> 5] |= 1u << (rowidx & 31);
-                ++ndefer;
+            if (!go) {
+                if (lo > hi) {
+                    // no value at this timepoint (every curve NaN): nothing is contained, nothing to rank
+                    if constexpr (J == 0) {
+#pragma unroll
+                        for (int e = 0; e < E; ++e)
+                            if (e < E - 1 || t + (E - 1) * NT < n) ABimg[r * n + t + e * NT] = RB_AB_SPECIAL;
+                        if (t == 0) nnan_img[r] = (u32)n;
+                    }
+                } else {                                              // set aside: sorted behind the loop
+                    if (t == 0) defer[rowidx >> 5] |= 1u << (rowidx & 31);
+                    ++ndefer;
+                }
             }
         }
         ++rowidx;

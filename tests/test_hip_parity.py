@@ -334,6 +334,7 @@ def test_bucket_kernel_tie_rows(eng, oracle, n):
     X[4::8][rng.random(X[4::8].shape) < 0.1] = np.nan                         # pure with NaNs
     X[5, :] = 3.0
     X[5, ::3] = np.nan
+    X[6, :] = np.nan                                                          # no value at all: skipped
     tg = np.unique(rng.integers(0, n, size=60))
     for J in (2, 3, 4):
         got = eng.mbd_counts(X, None, J, algo="rank")[tg]
