@@ -47,6 +47,9 @@ constexpr u32 RB_ROW_DEFERRED = 0xFFFFFFFFu;
 #ifndef RB_REDIRECT
 #define RB_REDIRECT 1
 #endif
+#ifndef RB_ROBUST
+#define RB_ROBUST 1                            // outlier-robust initial range from the waves' extremes
+#endif
 #ifndef RB_TIES
 #define RB_TIES 1
 #endif
@@ -249,6 +252,22 @@ __global__ __launch_bounds__(NT, RB_WAVES_PER_EU(E)) void rank_bucket_kernel(con
             const double2 p = reinterpret_cast<const double2 *>(redp)[lane & 15];
             lo = rb_readlane_f64(rb_row_allreduce<false>(p.x), 0);
             hi = rb_readlane_f64(rb_row_allreduce<true>(p.y), 0);
+            if constexpr (E >= 2 && RB_ROBUST) {
+                // Outlying curves (what depth analysis looks for) stretch the range and squeeze everyone else into
+                // a few buckets.  The 16 waves hold 16 random subsets of the row: the innermost of their minima and
+                // of their maxima bracket the bulk whatever a few waves contain.  When the full range is more than
+                // twice that bracket (widened by a quarter on either side) the bracket is the range: the tails
+                // clamp into the end buckets -- the map is monotone for ANY lo and scale.  Heuristic values: float.
+                const float l2 = rb_row_allreduce_f32<true>((float)p.x), h2 = rb_row_allreduce_f32<false>((float)p.y);
+                const double lo2 = (double)__int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(l2)));
+                const double hi2 = (double)__int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(h2)));
+                const double sp = hi2 - lo2;
+                if (sp > 0.0 && sp < INF && (hi - lo) > 3.0 * sp) {  // block-uniform
+                    const double nlo = lo2 - 0.25 * sp, nhi = hi2 + 0.25 * sp;
+                    lo = nlo > lo ? nlo : lo;
+                    hi = nhi < hi ? nhi : hi;
+                }
+            }
         }
         // range overflow -> 0 -> one crowded bucket; all values equal -> 0 -> one bucket of one value (closed form below)
         const double scale = (hi > lo) ? (double)NB / (hi - lo) : 0.0;
@@ -262,14 +281,15 @@ __global__ __launch_bounds__(NT, RB_WAVES_PER_EU(E)) void rank_bucket_kernel(con
         // block-uniform: a bucket above CAP keys / a bucket of 2^TRYB keys or more (ties?  see the member phase)
         bool crowded = false, trypure = false;
         if (go) {
-            // ---- (1) bucket + slot, branch-free.  min(fl(fl(x - lo) * scale), NB-1) is non-decreasing in x;
-            //      NaNs count into a dummy word behind the histogram ----
+            // ---- (1) bucket + slot, branch-free.  min(fl(fl(x - lo) * scale), NB-1), negative -> 0, is non-decreasing
+            //      in x for ANY lo and scale >= 0; NaNs count into a dummy word behind the histogram ----
 #pragma unroll
             for (int e = 0; e < E; ++e) {
                 const double x = k[e];
                 double u = (x - lo) * scale;
                 u = u < (double)(NB - 1) ? u : (double)(NB - 1);      // NaN -> NB-1 (overridden below)
-                u32 b = (u32)u;
+                u32 b;
+                asm("v_cvt_u32_f64 %0, %1" : "=v"(b) : "v"(u));       // saturating: below the range -> bucket 0
                 b = (x == x) ? b : (u32)(NB + 2);
                 const u32 sh = (b & 1u) * 16u;
                 const u32 old = atomicAdd(&H[b >> 1], 1u << sh);

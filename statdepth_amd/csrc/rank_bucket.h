@@ -75,4 +75,24 @@ __device__ __forceinline__ double rb_wave_allreduce(double v) {
 }
 
 
+// max (or min) over each row of 16 lanes of a FLOAT, in every lane of the row: the rotation is a DPP modifier of the
+// v_max_f32 / v_min_f32 itself (one instruction per step; s_nop: a DPP source written by the previous VALU needs two
+// wait states).  For heuristics only -- the values are rounded.
+template <bool MAX>
+__device__ __forceinline__ float rb_row_allreduce_f32(float v) {
+    if constexpr (MAX)
+        asm("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_ror:1 row_mask:0xf bank_mask:0xf\n\t"
+            "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_ror:2 row_mask:0xf bank_mask:0xf\n\t"
+            "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+            "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf"
+            : "+v"(v));
+    else
+        asm("s_nop 1\n\tv_min_f32_dpp %0, %0, %0 row_ror:1 row_mask:0xf bank_mask:0xf\n\t"
+            "s_nop 1\n\tv_min_f32_dpp %0, %0, %0 row_ror:2 row_mask:0xf bank_mask:0xf\n\t"
+            "s_nop 1\n\tv_min_f32_dpp %0, %0, %0 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+            "s_nop 1\n\tv_min_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf"
+            : "+v"(v));
+    return v;
+}
+
 }  // namespace sd

@@ -341,6 +341,30 @@ def test_bucket_kernel_tie_rows(eng, oracle, n):
         assert (got == oracle.mbd_counts(X, tg, J)).all(), J
 
 
+@pytest.mark.parametrize("n", [1500, 3000, 10000, 16384])
+def test_bucket_kernel_outlier_rows(eng, oracle, n):
+    """Far-out values stretch a row's range: the kernel takes the bracket of the waves' innermost extremes as the range
+    and clamps the tails into the end buckets (monotone for any range).  A few outlying curves, infinities, an
+    overflowing range, outliers in every wave, outliers tied with each other."""
+    rng = np.random.default_rng(n + 5)
+    T = 24
+    X = rng.normal(size=(T, n)).cumsum(axis=0)
+    X[:, :3] *= 1e6                                               # three outlying curves (one wave)
+    X[2, 7] = np.inf
+    X[2, 8] = -np.inf
+    X[3, 9] = 1.7e308
+    X[3, 10] = -1.7e308                                           # hi - lo overflows
+    X[4, rng.choice(n, size=n // 50, replace=False)] *= 1e5       # 2 % outliers: every wave has some
+    X[5, 20:60] = 1e9                                             # tied outliers
+    X[6, 20:60] = -np.inf
+    X[7, ::2] = np.nan
+    X[8, 100:] = 0.25                                             # the bulk on one value, a few keys elsewhere
+    tg = np.unique(np.concatenate([np.arange(12), np.arange(20, 24), rng.integers(0, n, size=40)]))
+    for J in (2, 3, 4):
+        got = eng.mbd_counts(X, None, J, algo="rank")[tg]
+        assert (got == oracle.mbd_counts(X, tg, J)).all(), J
+
+
 @pytest.mark.parametrize("T", [2100, 4100, 8200])
 def test_bucket_kernel_accumulator_widths(eng, oracle, T):
     """n = 16000: 9 rows per workgroup -> 32-bit register accumulators and u32 partial totals; 17 rows -> 64-bit

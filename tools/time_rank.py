@@ -12,6 +12,12 @@ reps = int(sys.argv[3]) if len(sys.argv) > 3 else 30
 X = np.random.default_rng(1234).normal(size=(T, n)).cumsum(axis=0)
 if os.environ.get("SD_TIES"):
     X = np.round(X, 1)
+if os.environ.get("SD_OUTLIER"):                 # a few curves far outside the others' range
+    X[:, :int(os.environ["SD_OUTLIER"])] *= 1e6
+if os.environ.get("SD_OUTLIER_RANDOM"):          # ... at random positions (every wave of the bucket kernel gets some)
+    X[:, np.random.default_rng(9).choice(n, size=int(os.environ["SD_OUTLIER_RANDOM"]), replace=False)] *= 1e6
+if os.environ.get("SD_CAUCHY"):                  # heavy tails at every timepoint
+    X = np.random.default_rng(5).standard_cauchy(size=(T, n))
 Xd = engine.to_device_matrix(X)
 if os.environ.get("SD_RANK_IMPL"):
     print("SD_RANK_IMPL =", os.environ["SD_RANK_IMPL"])
