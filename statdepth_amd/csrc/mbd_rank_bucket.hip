@@ -684,6 +684,17 @@ __global__ __launch_bounds__(NT) void rank_external_kernel(const double *__restr
             const double2 p = reinterpret_cast<const double2 *>(redp)[lane & 15];
             lo = rb_readlane_f64(rb_row_allreduce<false>(p.x), 0);
             hi = rb_readlane_f64(rb_row_allreduce<true>(p.y), 0);
+            if constexpr (E >= 2 && RB_ROBUST) {                      // outlier-robust range, as in rank_bucket_kernel
+                const float l2 = rb_row_allreduce_f32<true>((float)p.x), h2 = rb_row_allreduce_f32<false>((float)p.y);
+                const double lo2 = (double)__int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(l2)));
+                const double hi2 = (double)__int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(h2)));
+                const double sp = hi2 - lo2;
+                if (sp > 0.0 && sp < INF && (hi - lo) > 3.0 * sp) {
+                    const double nlo = lo2 - 0.25 * sp, nhi = hi2 + 0.25 * sp;
+                    lo = nlo > lo ? nlo : lo;
+                    hi = nhi < hi ? nhi : hi;
+                }
+            }
         }
         double scale = (double)NB / (hi - lo);
         // equal values, an infinity in the range, a range too small or too large: everything into one bucket

@@ -157,6 +157,9 @@ def test_external_counts_rows_and_sizes(eng, oracle, monkeypatch, n, m):
     G[6, :] = np.nan
     G[7, :4] = [F[7].min() - 1.0, F[7].max() + 1.0, F[7].min(), F[7].max()]
     F[8, 1:] = np.nan                                            # a single value in the set
+    F[9, :2] *= 1e7                                              # outlying set curves: robust range, tails clamp
+    G[9, :2] = [F[9].max() * 2, F[9].min()]
+    F[10, 3] = 1e300; G[10, 3] = -1e300
     tg = np.unique(np.concatenate([np.arange(min(m, 6)), rng.integers(0, m, size=6), [m - 1]]))
     for J in (2, 3):
         got = eng.mbd_external_counts(F, G, J=J)
