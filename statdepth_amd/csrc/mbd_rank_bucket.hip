@@ -53,9 +53,6 @@ constexpr u32 RB_ROW_DEFERRED = 0xFFFFFFFFu;
 #ifndef RB_TIES
 #define RB_TIES 1
 #endif
-#ifndef RB_PIPE
-#define RB_PIPE 0
-#endif
 constexpr int RB_PAD = 8;                      // NaN sentinels behind the bucket-ordered keys (never < or <= anything)
 
 // ---------------------------------------------------------------------------------------------------
@@ -462,11 +459,11 @@ __global__ __launch_bounds__(NT, RB_WAVES_PER_EU(E)) void rank_bucket_kernel(con
             }
             bool more = false;
             if (mode == 0) {
-            // the reads of key e + 1 are issued before the compares of key e (two keys' windows in flight per lane).
-            // A lane whose bucket ends before a pair reads the NaN pair behind the keys instead: same counts (NaN
-            // compares false), and lanes sharing one address cost no bank-conflict cycles.
-            double xw[2];
-            double2 yw[2][U2];
+            // A key's window: its reads are issued together, ahead of the compares.  A lane whose bucket ends before
+            // a pair reads the NaN pair behind the keys instead: same counts (NaN compares false), and lanes sharing
+            // one address cost no bank-conflict cycles.  (Two windows in flight per lane: no faster, see DESIGN.)
+            double xw[1];
+            double2 yw[1][U2];
             auto window = [&](int e, int w) {
                 const u32 base = bc[e] & 0xFFFFu, cnt = (bc[e] >> 16) & 0xFFu, slot = bc[e] >> 24;
                 const u32 odd = base & 1u;
@@ -484,8 +481,7 @@ __global__ __launch_bounds__(NT, RB_WAVES_PER_EU(E)) void rank_bucket_kernel(con
             window(0, 0);
 #pragma unroll
             for (int e = 0; e < E; ++e) {
-                if (RB_PIPE && e + 1 < E) window(e + 1, (e + 1) & 1);
-                const int w = RB_PIPE ? (e & 1) : 0;
+                const int w = 0;
                 const u32 base = bc[e] & 0xFFFFu, cnt = (bc[e] >> 16) & 0xFFu;
                 const u32 odd = base & 1u;
                 const double x = xw[w];
@@ -499,7 +495,7 @@ __global__ __launch_bounds__(NT, RB_WAVES_PER_EU(E)) void rank_bucket_kernel(con
                 }
                 pk[e] = (less - odd) | ((le - odd) << 16);
                 more |= cnt + odd > (u32)(2 * U2);
-                if (!RB_PIPE && e + 1 < E) window(e + 1, 0);
+                if (e + 1 < E) window(e + 1, 0);
             }
             if (__ballot(more && !(DBG == 6 && n > 0)) != 0) {   // DBG 6: never taken, code kept (timing experiment)
 #pragma unroll
