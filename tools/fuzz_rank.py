@@ -23,6 +23,15 @@ for c in range(cases):
     elif kind == "lognormal": X = np.exp(X * 5)
     elif kind == "tiny": X = X * 1e-312
     elif kind == "huge": X = X * 1e307
+    # outlying curves / entries (robust range), values a hair apart (mixed buckets), blocks of equal values inside
+    # continuous rows (tie path with and without crowding)
+    if rng.random() < 0.35: X[:, rng.choice(n, size=min(n, int(rng.choice([1, 3, 17, max(1, n // 50)]))), replace=False)] *= rng.choice([1e3, 1e6, 1e12])
+    if rng.random() < 0.2: X[rng.random(X.shape) < 0.002] *= -1e8
+    if rng.random() < 0.25:
+        w = int(rng.integers(2, max(3, min(n, 400))))
+        c0 = int(rng.integers(0, max(1, n - w)))
+        v = X[:, c0:c0 + 1].copy()
+        X[:, c0:c0 + w] = np.where(rng.random((T, min(w, n - c0))) < 0.5, v, v * (1 + rng.choice([0.0, 1e-15, 1e-12])))
     if rng.random() < 0.4: X[rng.random(X.shape) < rng.choice([0.0005, 0.02, 0.5])] = np.nan
     if rng.random() < 0.3: X[rng.random(X.shape) < 0.001] = np.inf
     if rng.random() < 0.3: X[rng.random(X.shape) < 0.001] = -np.inf
