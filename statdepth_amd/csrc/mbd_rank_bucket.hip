@@ -50,6 +50,13 @@ constexpr u32 RB_ROW_DEFERRED = 0xFFFFFFFFu;
 #ifndef RB_ROBUST
 #define RB_ROBUST 1                            // outlier-robust initial range from the waves' extremes
 #endif
+// The bracket, widened by RB_ROBUST_MARGIN brackets on either side, replaces the range when the range is more than
+// RB_ROBUST_RATIO brackets wide.  The margin is generous on purpose: the bracket is the bulk's +-2.5 sigma only when the
+// waves hold random subsets; curves ordered by level make them stratified and the bracket as narrow as the 9 % .. 93 %
+// quantiles, and then a tight margin would clamp a tail of hundreds of keys into each end bucket (a set-aside row).
+// With 1.5 the bulk still gets a quarter of the buckets or more, and a misfire on stratified heavy-tailed data is mild.
+#define RB_ROBUST_RATIO 8.0
+#define RB_ROBUST_MARGIN 1.5
 #ifndef RB_TIES
 #define RB_TIES 1
 #endif
@@ -253,14 +260,14 @@ __global__ __launch_bounds__(NT, RB_WAVES_PER_EU(E)) void rank_bucket_kernel(con
                 // Outlying curves (what depth analysis looks for) stretch the range and squeeze everyone else into
                 // a few buckets.  The 16 waves hold 16 random subsets of the row: the innermost of their minima and
                 // of their maxima bracket the bulk whatever a few waves contain.  When the full range is more than
-                // twice that bracket (widened by a quarter on either side) the bracket is the range: the tails
+                // RB_ROBUST_RATIO times that bracket, the widened bracket is the range (see RB_ROBUST_MARGIN): the tails
                 // clamp into the end buckets -- the map is monotone for ANY lo and scale.  Heuristic values: float.
                 const float l2 = rb_row_allreduce_f32<true>((float)p.x), h2 = rb_row_allreduce_f32<false>((float)p.y);
                 const double lo2 = (double)__int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(l2)));
                 const double hi2 = (double)__int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(h2)));
                 const double sp = hi2 - lo2;
-                if (sp > 0.0 && sp < INF && (hi - lo) > 3.0 * sp) {  // block-uniform
-                    const double nlo = lo2 - 0.25 * sp, nhi = hi2 + 0.25 * sp;
+                if (sp > 0.0 && sp < INF && (hi - lo) > RB_ROBUST_RATIO * sp) {  // block-uniform
+                    const double nlo = lo2 - RB_ROBUST_MARGIN * sp, nhi = hi2 + RB_ROBUST_MARGIN * sp;
                     lo = nlo > lo ? nlo : lo;
                     hi = nhi < hi ? nhi : hi;
                 }
@@ -685,8 +692,8 @@ __global__ __launch_bounds__(NT) void rank_external_kernel(const double *__restr
                 const double lo2 = (double)__int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(l2)));
                 const double hi2 = (double)__int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(h2)));
                 const double sp = hi2 - lo2;
-                if (sp > 0.0 && sp < INF && (hi - lo) > 3.0 * sp) {
-                    const double nlo = lo2 - 0.25 * sp, nhi = hi2 + 0.25 * sp;
+                if (sp > 0.0 && sp < INF && (hi - lo) > RB_ROBUST_RATIO * sp) {
+                    const double nlo = lo2 - RB_ROBUST_MARGIN * sp, nhi = hi2 + RB_ROBUST_MARGIN * sp;
                     lo = nlo > lo ? nlo : lo;
                     hi = nhi < hi ? nhi : hi;
                 }

@@ -12,8 +12,12 @@ reps = int(sys.argv[3]) if len(sys.argv) > 3 else 30
 X = np.random.default_rng(1234).normal(size=(T, n)).cumsum(axis=0)
 if os.environ.get("SD_TIES"):
     X = np.round(X, 1)
+if os.environ.get("SD_SORTED"):                  # curves ordered by level (normal / t3): the waves' subsets are stratified
+    g = np.random.default_rng(3)
+    lev = np.sort(g.normal(size=n) if os.environ["SD_SORTED"] == "normal" else g.standard_t(3, size=n))
+    X = lev[None, :] * 30.0 + X * 0.05
 if os.environ.get("SD_OUTLIER"):                 # a few curves far outside the others' range
-    X[:, :int(os.environ["SD_OUTLIER"])] *= 1e6
+    X[:, :int(os.environ["SD_OUTLIER"])] *= float(os.environ.get("SD_OUTLIER_SCALE", "1e6"))
 if os.environ.get("SD_OUTLIER_RANDOM"):          # ... at random positions (every wave of the bucket kernel gets some)
     X[:, np.random.default_rng(9).choice(n, size=int(os.environ["SD_OUTLIER_RANDOM"]), replace=False)] *= 1e6
 if os.environ.get("SD_CAUCHY"):                  # heavy tails at every timepoint
