@@ -36,7 +36,6 @@
 namespace sd {
 
 constexpr u32 RB_AB_SPECIAL = 0xFFFFFFFFu;     // same encodings as mbd_rank_ab.hip
-constexpr u32 RB_ROW_DEFERRED = 0xFFFFFFFFu;
 // RB_SMALL_E > 0 builds the kernels with at most that many keys per thread for 64 VGPRs and launches two workgroups
 // (two rows) per CU.  Measured (n = 600..4096, T = 1000): no faster than one workgroup per CU -- the kernel is bound
 // by VALU + LDS throughput, not by latency or barrier stalls -- so it is off.
@@ -45,7 +44,7 @@ constexpr u32 RB_ROW_DEFERRED = 0xFFFFFFFFu;
 #endif
 #define RB_WAVES_PER_EU(E) ((E) <= RB_SMALL_E ? 8 : 4)
 #ifndef RB_REDIRECT
-#define RB_REDIRECT 1
+#define RB_REDIRECT 1                          // window reads a bucket does not need go to one shared NaN pair
 #endif
 #ifndef RB_ROBUST
 #define RB_ROBUST 1                            // outlier-robust initial range from the waves' extremes
@@ -58,12 +57,12 @@ constexpr u32 RB_ROW_DEFERRED = 0xFFFFFFFFu;
 #define RB_ROBUST_RATIO 8.0
 #define RB_ROBUST_MARGIN 1.5
 #ifndef RB_TIES
-#define RB_TIES 1
+#define RB_TIES 1                              // tie-heavy rows: closed form when every bucket holds one value
 #endif
 constexpr int RB_PAD = 8;                      // NaN sentinels behind the bucket-ordered keys (never < or <= anything)
 
 // ---------------------------------------------------------------------------------------------------
-// The row the bucket map cannot spread (an infinity, all values equal, a crowded bucket): in-LDS sort of the
+// The row the bucket map cannot spread (an infinite bracket, a crowded bucket that mixes values): in-LDS sort of the
 // plain values + binary search, the method of rank_search_kernel (mbd_rank_ab.hip), for ONE row inside the
 // bucket kernel, run behind the main row loop for the rows it set aside.  Thread t gets the pairs
 // of its curves t + 1024 e in ab[e] (B | A << 16, RB_AB_SPECIAL where the curve is NaN or beyond n).
