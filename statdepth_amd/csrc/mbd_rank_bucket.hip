@@ -932,7 +932,7 @@ static int launch_bucket_cfg(const double *Y, i64 n, i64 row0, i64 rows, u64 *pa
     if constexpr (J == 2) {
         if (p32 == 2) kf = rank_bucket_kernel<NT, E, LNB, J, RB_CAP, U2, 0, true>;
     }
-    if constexpr (E == 10 && J == 2 && LNB == 14 && U2 == 3) {
+    if constexpr (E == 10 && J == 2 && LNB == 15 && U2 == 3) {
         if (const char *d = getenv("SD_RB_DBG")) {        // timing experiments: truncated kernels
             switch (atoi(d)) {
                 case 1: kf = rank_bucket_kernel<NT, E, LNB, J, RB_CAP, U2, 1>; break;
@@ -954,17 +954,19 @@ static int launch_bucket_cfg(const double *Y, i64 n, i64 row0, i64 rows, u64 *pa
 
 template <int J>
 static int launch_bucket_j(const double *Y, i64 n, i64 row0, i64 rows, u64 *partial, int p32, int G, hipStream_t s) {
-    // E = ceil(n / 1024); 16384 buckets while keys + histogram fit the 160 KiB of LDS, 8192 above;
-    // first member pass: 3 x 16 bytes
+    // E = ceil(n / 1024); 8192 buckets up to n = 4096, 16384 above while keys + histogram fit the 160 KiB of LDS
+    // (8192 at E = 16), 32768 at E = 10, 11 for J = 2 and the pair-image mode (measured: -2..-3.5 % on continuous
+    // rows, -7 % with outlying curves, +6 % on tie-heavy rows whose closed form only pays the longer prefix sum;
+    // J = 3 stays at 16384: the wider prefix arrays push it further into scratch); first member pass: 3 x 16 bytes
 #define RB_ARGS Y, n, row0, rows, partial, p32, G, s
     const int E = (int)((n + 1023) / 1024);
     if (E == 10 && J == 2) {                              // tuning experiments on the config-2 shape
         const char *eu = getenv("SD_RB_U2"), *el = getenv("SD_RB_LNB");
-        const int u2 = eu ? atoi(eu) : 3, lnb = el ? atoi(el) : 14;
+        const int u2 = eu ? atoi(eu) : 3, lnb = el ? atoi(el) : 15;
         if (lnb == 14 && u2 == 2) return launch_bucket_cfg<1024, 10, 14, 2, 2>(RB_ARGS);
         if (lnb == 14 && u2 == 4) return launch_bucket_cfg<1024, 10, 14, 2, 4>(RB_ARGS);
         if (lnb == 15 && u2 == 2) return launch_bucket_cfg<1024, 10, 15, 2, 2>(RB_ARGS);
-        if (lnb == 15 && u2 == 3) return launch_bucket_cfg<1024, 10, 15, 2, 3>(RB_ARGS);
+        if (lnb == 14 && u2 == 3) return launch_bucket_cfg<1024, 10, 14, 2, 3>(RB_ARGS);
         if (lnb == 13 && u2 == 3) return launch_bucket_cfg<1024, 10, 13, 2, 3>(RB_ARGS);
         if (lnb == 13 && u2 == 4) return launch_bucket_cfg<1024, 10, 13, 2, 4>(RB_ARGS);
     }
@@ -978,8 +980,8 @@ static int launch_bucket_j(const double *Y, i64 n, i64 row0, i64 rows, u64 *part
         case 7: return launch_bucket_cfg<1024, 7, 14, J, 3>(RB_ARGS);
         case 8: return launch_bucket_cfg<1024, 8, 14, J, 3>(RB_ARGS);
         case 9: return launch_bucket_cfg<1024, 9, 14, J, 3>(RB_ARGS);
-        case 10: return launch_bucket_cfg<1024, 10, 14, J, 3>(RB_ARGS);
-        case 11: return launch_bucket_cfg<1024, 11, 14, J, 3>(RB_ARGS);
+        case 10: return launch_bucket_cfg<1024, 10, (J == 3 ? 14 : 15), J, 3>(RB_ARGS);
+        case 11: return launch_bucket_cfg<1024, 11, (J == 3 ? 14 : 15), J, 3>(RB_ARGS);
         case 12: return launch_bucket_cfg<1024, 12, 14, J, 3>(RB_ARGS);
         case 13: return launch_bucket_cfg<1024, 13, 14, J, 3>(RB_ARGS);
         case 14: return launch_bucket_cfg<1024, 14, 14, J, 3>(RB_ARGS);
@@ -999,7 +1001,7 @@ int launch_rank_bucket_image(const double *Y, i64 n, i64 row0, i64 rows, u32 *AB
 #define RB_IM(E_, L_) case E_: return launch_bucket_cfg<1024, E_, L_, 0, 3>(Y, n, row0, rows, img, 0, G, s, nnan);
     switch ((int)((n + 1023) / 1024)) {
         RB_IM(1, 13) RB_IM(2, 13) RB_IM(3, 13) RB_IM(4, 13) RB_IM(5, 14) RB_IM(6, 14) RB_IM(7, 14) RB_IM(8, 14)
-        RB_IM(9, 14) RB_IM(10, 14) RB_IM(11, 14) RB_IM(12, 14) RB_IM(13, 14) RB_IM(14, 14) RB_IM(15, 14) RB_IM(16, 13)
+        RB_IM(9, 14) RB_IM(10, 15) RB_IM(11, 15) RB_IM(12, 14) RB_IM(13, 14) RB_IM(14, 14) RB_IM(15, 14) RB_IM(16, 13)
     }
 #undef RB_IM
     return fail(SD_ERR_UNSUPPORTED, "bucket kernel covers n <= 16384");
