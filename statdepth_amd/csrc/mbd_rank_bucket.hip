@@ -899,10 +899,13 @@ __global__ __launch_bounds__(256) void rank_finalize4_kernel(const u32 *__restri
 // host side
 // ---------------------------------------------------------------------------------------------------
 static int rb_cus() {
+    static int cached[64];                                // per device; 0 = not asked yet (benign race: same value)
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) {
+        if (dev >= 0 && dev < 64 && cached[dev] > 0) return cached[dev];
         int v = 0;
         if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+        if (dev >= 0 && dev < 64) cached[dev] = cus;
     }
     return cus;
 }
