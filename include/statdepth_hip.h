@@ -152,6 +152,17 @@ int sd_bd_strict_j_counts(const double *X, int64_t T, int64_t n, int64_t st, int
 int sd_l1_depth(const double *P, int64_t n, int d, const int64_t *targets, int64_t m,
                 double *out, void *stream);
 
+/* The same depth for m EXTERNAL points Q (m x d): every row of P is an "other" and the sample counts n + 1 points --
+ * what the reference's point-cloud homogeneity does once per point of G with a temporary row
+ * (homogeneity.py:172-175,183-186: append g to F, PointcloudDepth(to_compute=[g]), drop g); here one launch for all. */
+int sd_l1_external_depth(const double *P, int64_t n, int d, const double *Q, int64_t m, double *out, void *stream);
+/* ... and inside explicit BLOCKS of rows, nb (block, target) pairs in one launch: the K-block sampled estimator
+ * (_samplepointwisedepth, _pointcloud.py:107-121) calls _pointwisedepth on len(to_compute) * (n // K) samples.
+ * members: int32[nb*bs] row indices, -1 = padding; in every block the OTHER rows first and the target LAST.
+ * out[k] = 1 - ||sum over the block's others|| / (block size). */
+int sd_l1_subset_depth(const double *P, int64_t n, int d, const int32_t *members, int64_t nb, int bs, double *out,
+                       void *stream);
+
 /* ---- K4: simplex containment counts ---------------------------------------------
  * Replaces: _is_in_simplex (_containment.py:138-176, an LP feasibility test
  * through scipy.optimize.linprog) inside
@@ -174,6 +185,16 @@ int sd_pointcloud_simplex_counts(const double *P, int64_t n, int d,
 int sd_multi_simplex_counts(const double *P, int64_t n, int64_t T, int d,
                             const int64_t *targets, int64_t m, int relax, double tol,
                             int64_t *out, void *stream);
+
+/* External targets / explicit blocks, as for sd_l1_external_depth / sd_l1_subset_depth above:
+ *   out[q] = #{(d+1)-subsets of ALL n rows of P whose simplex contains Q[q]}; depth = out / C(n+1, d+1) on the host
+ *   (_pointcloud.py:38,56 with the temporary row counted: homogeneity.py:172-175,183-186);
+ *   out[k] = #{(d+1)-subsets of block k's other rows whose simplex contains the block's target (its last row)};
+ *   depth = out / C(block size, d+1) (_pointcloud.py:107-121 -> :50-56 on the sample). */
+int sd_pointcloud_simplex_external_counts(const double *P, int64_t n, int d, const double *Q, int64_t m, double tol,
+                                          int64_t *out, void *stream);
+int sd_pointcloud_simplex_subset_counts(const double *P, int64_t n, int d, const int32_t *members, int64_t nb, int bs,
+                                        double tol, int64_t *out, void *stream);
 
 /* Seeded uniform subset-sampling estimators for sizes where exhaustive
  * enumeration is impossible (BASELINE.json configs 4 and 5; not in the

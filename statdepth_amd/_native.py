@@ -42,6 +42,10 @@ SIGNATURES = {
     "sd_bd_strict_j_workspace_bytes": (_sz, [_i64, _i64, _i64, _i64, _i64, _int]),
     "sd_bd_strict_j_counts": (_int, [_vp, _i64, _i64, _i64, _i64, _vp, _i64, _int, _vp, _vp, _sz, _vp]),
     "sd_l1_depth": (_int, [_vp, _i64, _int, _vp, _i64, _vp, _vp]),
+    "sd_l1_external_depth": (_int, [_vp, _i64, _int, _vp, _i64, _vp, _vp]),
+    "sd_l1_subset_depth": (_int, [_vp, _i64, _int, _vp, _i64, _int, _vp, _vp]),
+    "sd_pointcloud_simplex_external_counts": (_int, [_vp, _i64, _int, _vp, _i64, _dbl, _vp, _vp]),
+    "sd_pointcloud_simplex_subset_counts": (_int, [_vp, _i64, _int, _vp, _i64, _int, _dbl, _vp, _vp]),
     "sd_pointcloud_simplex_counts": (_int, [_vp, _i64, _int, _vp, _i64, _dbl, _vp, _vp]),
     "sd_multi_simplex_counts": (_int, [_vp, _i64, _i64, _int, _vp, _i64, _int, _dbl, _vp, _vp]),
     "sd_pointcloud_simplex_sampled": (_int, [_vp, _i64, _int, _vp, _i64, _dbl, _i64, _u64, _vp, _vp]),

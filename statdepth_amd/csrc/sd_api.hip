@@ -318,6 +318,23 @@ int sd_l1_depth(const double *P, int64_t n, int d, const int64_t *targets, int64
     return launch_l1_depth(P, n, d, targets, m, out, (hipStream_t)stream);
 }
 
+int sd_l1_external_depth(const double *P, int64_t n, int d, const double *Q, int64_t m, double *out, void *stream) {
+    if (!P || !Q || !out) return fail(SD_ERR_INVALID, "null pointer");
+    if (n <= 0 || d <= 0 || m < 0) return fail(SD_ERR_INVALID, "bad shape");
+    if (d > 64) return fail(SD_ERR_UNSUPPORTED, "l1 depth covers d <= 64");
+    if (m == 0) return SD_OK;
+    return launch_l1_external(P, n, d, Q, m, out, (hipStream_t)stream);
+}
+
+int sd_l1_subset_depth(const double *P, int64_t n, int d, const int32_t *members, int64_t nb, int bs, double *out,
+                       void *stream) {
+    if (!P || !members || !out) return fail(SD_ERR_INVALID, "null pointer");
+    if (n <= 0 || d <= 0 || nb < 0 || bs <= 0) return fail(SD_ERR_INVALID, "bad shape");
+    if (d > 64) return fail(SD_ERR_UNSUPPORTED, "l1 depth covers d <= 64");
+    if (nb == 0) return SD_OK;
+    return launch_l1_subsets(P, n, d, members, nb, bs, out, (hipStream_t)stream);
+}
+
 // ---------------------------------------------------------------------------
 // K4
 // ---------------------------------------------------------------------------
@@ -351,6 +368,26 @@ int sd_pointcloud_simplex_sampled(const double *P, int64_t n, int d, const int64
     if (n - 1 < d + 1) return fail(SD_ERR_INVALID, "need at least d+2 points");
     if (m == 0) return SD_OK;
     return launch_pointcloud_simplex(P, n, d, targets, m, tol, samples, seed, (u64 *)out, (hipStream_t)stream);
+}
+
+int sd_pointcloud_simplex_external_counts(const double *P, int64_t n, int d, const double *Q, int64_t m, double tol,
+                                          int64_t *out, void *stream) {
+    if (!Q) return fail(SD_ERR_INVALID, "null pointer");
+    int rc = check_simplex(P, n, d, (const i64 *)1, m, out, true, n);
+    if (rc) return rc;
+    if (m < 0) return fail(SD_ERR_INVALID, "m < 0");
+    if (m == 0) return SD_OK;
+    return launch_pointcloud_simplex_external(P, n, d, Q, m, tol, (u64 *)out, (hipStream_t)stream);
+}
+
+int sd_pointcloud_simplex_subset_counts(const double *P, int64_t n, int d, const int32_t *members, int64_t nb, int bs,
+                                        double tol, int64_t *out, void *stream) {
+    if (!members) return fail(SD_ERR_INVALID, "null pointer");
+    if (bs <= 0 || nb < 0) return fail(SD_ERR_INVALID, "bad shape");
+    int rc = check_simplex(P, n, d, (const i64 *)1, nb, out, true, bs - 1);
+    if (rc) return rc;
+    if (nb == 0) return SD_OK;
+    return launch_pointcloud_simplex_subsets(P, n, d, members, nb, bs, tol, (u64 *)out, (hipStream_t)stream);
 }
 
 int sd_multi_simplex_counts(const double *P, int64_t n, int64_t T, int d, const int64_t *targets, int64_t m,

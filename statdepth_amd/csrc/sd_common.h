@@ -77,7 +77,13 @@ int launch_bd_strict(const double *Y, i64 T, i64 n, const i64 *targets, i64 m, i
                      u64 *out, void *ws, size_t ws_bytes, hipStream_t s);
 // K5 l1
 int launch_l1_depth(const double *P, i64 n, int d, const i64 *targets, i64 m, double *out, hipStream_t s);
+int launch_l1_external(const double *P, i64 n, int d, const double *Q, i64 m, double *out, hipStream_t s);
+int launch_l1_subsets(const double *P, i64 n, int d, const int *members, i64 nb, int bs, double *out, hipStream_t s);
 // K4 simplex
+int launch_pointcloud_simplex_external(const double *P, i64 n, int d, const double *Q, i64 m, double tol, u64 *out,
+                                       hipStream_t s);
+int launch_pointcloud_simplex_subsets(const double *P, i64 n, int d, const int *members, i64 nb, int bs, double tol,
+                                      u64 *out, hipStream_t s);
 int launch_pointcloud_simplex(const double *P, i64 n, int d, const i64 *targets, i64 m, double tol,
                               i64 samples, u64 seed, u64 *out, hipStream_t s);
 int launch_multi_simplex(const double *P, i64 n, i64 T, int d, const i64 *targets, i64 m, int relax,

@@ -179,16 +179,71 @@ __device__ __forceinline__ u64 block_sum_u64(u64 v, u64 *scratch) {
     return r;
 }
 
+// Which rows of P a block's subsets are drawn from, and where its target lies:
+//   default   -- the n - 1 rows other than targets[q] (the subset loops of _pointwisedepth / _simplex_depth);
+//   members   -- an explicit block of rows per target (int32[nb][bs], -1 padded; the block's OTHERS first, its target
+//                LAST): the K-block sampled estimator (_samplepointwisedepth, _pointcloud.py:107-121) in one launch;
+//   Q         -- EXTERNAL targets (m x d): every row of P is an "other" (the homogeneity coefficients' depth of a
+//                point of G inside F u {g}, homogeneity.py:172-186, for all of G at once).  Point clouds only (T = 0).
+struct SxSel {
+    const int *members;
+    int bs;
+    const double *Q;
+    int d;
+};
+
+struct SxBlock {
+    const int *mem;
+    const double *xq;
+    i64 tg, no;
+    u64 total, key;
+};
+
+__device__ __forceinline__ SxBlock sx_block(const SxSel &sel, const i64 *targets, i64 n, i64 q, int k, u64 total) {
+    SxBlock b;
+    b.mem = nullptr;
+    b.xq = nullptr;
+    if (sel.members) {
+        const int *mem = sel.members + q * sel.bs;
+        int cnt = 0;
+        while (cnt < sel.bs && mem[cnt] >= 0) ++cnt;
+        b.mem = mem;
+        b.no = cnt > 0 ? cnt - 1 : 0;
+        b.tg = cnt > 0 ? mem[cnt - 1] : 0;
+        b.total = cnt > 0 ? binom_dev((u64)b.no, k) : 0;        // exhaustive inside the block
+        b.key = (u64)b.tg;
+    } else if (sel.Q) {
+        b.xq = sel.Q + q * sel.d;
+        b.no = n;
+        b.tg = -1;
+        b.total = total;
+        b.key = (u64)(n + q);
+    } else {
+        b.tg = targets ? targets[q] : q;
+        b.no = n - 1;
+        b.total = total;
+        b.key = (u64)b.tg;
+    }
+    return b;
+}
+
+__device__ __forceinline__ i64 sx_src(const SxBlock &b, i64 i) {
+    if (b.mem) return b.mem[i];
+    if (b.xq) return i;
+    return i < b.tg ? i : i + 1;                                 // skip the target itself
+}
+
 // grid = (chunks, m).  T == 0 selects the pointcloud form (P is n x d);
 // otherwise P is n x T x d and c counts timepoints (relax / strict reduction).
 __global__ __launch_bounds__(SX_THREADS) void simplex_kernel(
     const double *__restrict__ P, i64 n, i64 T, int d, const i64 *__restrict__ targets, int relax, double tol,
-    u64 total, u64 per_thread, i64 samples, u64 seed, i64 q0, u64 *__restrict__ out) {
+    u64 total, u64 per_thread, i64 samples, u64 seed, i64 q0, u64 *__restrict__ out, SxSel sel) {
     __shared__ u64 scratch[SX_THREADS / 64];
     i64 q = q0 + blockIdx.y;
-    i64 tg = targets ? targets[q] : q;
     int k = d + 1;
-    i64 no = n - 1;
+    const SxBlock blk = sx_block(sel, targets, n, q, k, total);
+    const i64 tg = blk.tg, no = blk.no;
+    total = blk.total;
     u64 tid = (u64)blockIdx.x * SX_THREADS + threadIdx.x;
     u64 first = tid * per_thread;
     u64 acc = 0;
@@ -199,15 +254,15 @@ __global__ __launch_bounds__(SX_THREADS) void simplex_kernel(
         if (samples < 0) unrank_comb(first, k, no, idx);
         i64 TT = T > 0 ? T : 1;
         for (u64 r = first; r < last; ++r) {
-            if (samples >= 0) sample_subset(seed, (u64)tg, r, k, no, idx);
+            if (samples >= 0) sample_subset(seed, blk.key, r, k, no, idx);
             u64 cnt = 0;
             for (i64 t = 0; t < TT; ++t) {
                 for (int c = 0; c < k; ++c) {
-                    i64 src = idx[c] < tg ? idx[c] : idx[c] + 1;     // skip the target itself
+                    i64 src = sx_src(blk, idx[c]);
                     const double *pp = P + (src * TT + t) * d;
                     for (int e = 0; e < d; ++e) pts[c * d + e] = pp[e];
                 }
-                const double *xx = P + (tg * TT + t) * d;
+                const double *xx = blk.xq ? blk.xq : P + (tg * TT + t) * d;
                 for (int e = 0; e < d; ++e) x[e] = xx[e];
                 cnt += point_in_hull(pts, k, d, x, tol);
             }
@@ -328,12 +383,13 @@ __device__ __forceinline__ int hull_full_rank(double (&R)[D + 1][D + 2], double 
 template <int D>
 __global__ __launch_bounds__(SX_THREADS) void simplex_kernel_fast(
     const double *__restrict__ P, i64 n, i64 T, const i64 *__restrict__ targets, int relax, double tol,
-    u64 total, u64 per_thread, i64 samples, u64 seed, i64 q0, u64 *__restrict__ out) {
+    u64 total, u64 per_thread, i64 samples, u64 seed, i64 q0, u64 *__restrict__ out, SxSel sel) {
     __shared__ u64 scratch[SX_THREADS / 64];
     constexpr int K = D + 1;
     const i64 q = q0 + blockIdx.y;
-    const i64 tg = targets ? targets[q] : q;
-    const i64 no = n - 1;
+    const SxBlock blk = sx_block(sel, targets, n, q, K, total);
+    const i64 tg = blk.tg, no = blk.no;
+    total = blk.total;
     const u64 tid = (u64)blockIdx.x * SX_THREADS + threadIdx.x;
     const u64 first = tid * per_thread;
     u64 acc = 0;
@@ -343,16 +399,16 @@ __global__ __launch_bounds__(SX_THREADS) void simplex_kernel_fast(
         if (samples < 0) unrank_comb(first, K, no, idx);
         const i64 TT = T > 0 ? T : 1;
         for (u64 r = first; r < last; ++r) {
-            if (samples >= 0) sample_subset(seed, (u64)tg, r, K, no, idx);
+            if (samples >= 0) sample_subset(seed, blk.key, r, K, no, idx);
             u64 cnt = 0;
             for (i64 t = 0; t < TT; ++t) {
                 double R[K][K + 1];
                 double scale = 1.0;
                 bool anynan = false;
-                const double *xx = P + (tg * TT + t) * D;
+                const double *xx = blk.xq ? blk.xq : P + (tg * TT + t) * D;
 #pragma unroll
                 for (int c = 0; c < K; ++c) {
-                    const i64 src = idx[c] < tg ? idx[c] : idx[c] + 1;     // skip the target itself
+                    const i64 src = sx_src(blk, idx[c]);
                     const double *pp = P + (src * TT + t) * D;
 #pragma unroll
                     for (int e = 0; e < D; ++e) {
@@ -375,7 +431,7 @@ __global__ __launch_bounds__(SX_THREADS) void simplex_kernel_fast(
                 if (res == 2) {                                         // degenerate simplex: generic code, from the data
                     double pts[SMAX * 8], x[8];
                     for (int c = 0; c < K; ++c) {
-                        const i64 src = idx[c] < tg ? idx[c] : idx[c] + 1;
+                        const i64 src = sx_src(blk, idx[c]);
                         const double *pp = P + (src * TT + t) * D;
                         for (int e = 0; e < D; ++e) pts[c * D + e] = pp[e];
                     }
@@ -394,11 +450,14 @@ __global__ __launch_bounds__(SX_THREADS) void simplex_kernel_fast(
 
 
 static int launch_simplex_common(const double *P, i64 n, i64 T, int d, const i64 *targets, i64 m, int relax,
-                                 double tol, i64 samples, u64 seed, u64 *out, hipStream_t s) {
+                                 double tol, i64 samples, u64 seed, u64 *out, hipStream_t s,
+                                 SxSel sel = SxSel{nullptr, 0, nullptr, 0}) {
     SD_HIP(hipMemsetAsync(out, 0, sizeof(u64) * m, s));
     u64 total;
+    // subsets per target: of the n - 1 others / of all n rows (external targets) / of the largest block's others
+    const i64 pool = sel.members ? (i64)sel.bs - 1 : (sel.Q ? n : n - 1);
     if (samples >= 0) total = (u64)samples;
-    else if (!binom_u64_checked((u64)(n - 1), d + 1, &total)) return fail(SD_ERR_OVERFLOW, "subset count overflow");
+    else if (!binom_u64_checked((u64)pool, d + 1, &total)) return fail(SD_ERR_OVERFLOW, "subset count overflow");
     if (total == 0) return SD_OK;
     // aim for ~2^18 threads over all targets, at least 1 subset per thread
     u64 want_threads = ((u64)1 << 18) / (u64)(m > 0 ? m : 1);
@@ -412,17 +471,17 @@ static int launch_simplex_common(const double *P, i64 n, i64 T, int d, const i64
         i64 mm = m - q0 < 65535 ? m - q0 : 65535;
         dim3 grid((unsigned)blocks, (unsigned)mm);
 #define SX_FAST(D_) case D_: hipLaunchKernelGGL((simplex_kernel_fast<D_>), grid, dim3(SX_THREADS), 0, s, P, n, T, targets, \
-                                                 relax, tol, total, per_thread, samples, seed, q0, out); break;
+                                                 relax, tol, total, per_thread, samples, seed, q0, out, sel); break;
         const char *eg = getenv("SD_SIMPLEX_GENERIC");       // 1: the generic (scratch-memory) kernel, cross-check
         if (eg && atoi(eg) == 1) {
             hipLaunchKernelGGL(simplex_kernel, grid, dim3(SX_THREADS), 0, s, P, n, T, d, targets, relax, tol, total,
-                               per_thread, samples, seed, q0, out);
+                               per_thread, samples, seed, q0, out, sel);
         } else {
             switch (d) {
                 SX_FAST(1) SX_FAST(2) SX_FAST(3) SX_FAST(4) SX_FAST(5) SX_FAST(6) SX_FAST(7) SX_FAST(8)
                 default:
                     hipLaunchKernelGGL(simplex_kernel, grid, dim3(SX_THREADS), 0, s, P, n, T, d, targets, relax, tol,
-                                       total, per_thread, samples, seed, q0, out);
+                                       total, per_thread, samples, seed, q0, out, sel);
             }
         }
 #undef SX_FAST
@@ -434,6 +493,18 @@ static int launch_simplex_common(const double *P, i64 n, i64 T, int d, const i64
 int launch_pointcloud_simplex(const double *P, i64 n, int d, const i64 *targets, i64 m, double tol,
                               i64 samples, u64 seed, u64 *out, hipStream_t s) {
     return launch_simplex_common(P, n, 0, d, targets, m, 1, tol, samples, seed, out, s);
+}
+
+// external targets Q (m x d): out[q] = #{(d+1)-subsets of ALL n rows of P whose simplex contains Q[q]}
+int launch_pointcloud_simplex_external(const double *P, i64 n, int d, const double *Q, i64 m, double tol, u64 *out,
+                                       hipStream_t s) {
+    return launch_simplex_common(P, n, 0, d, nullptr, m, 1, tol, -1, 0, out, s, SxSel{nullptr, 0, Q, d});
+}
+
+// explicit blocks: out[k] = #{(d+1)-subsets of block k's others whose simplex contains the block's target (its last row)}
+int launch_pointcloud_simplex_subsets(const double *P, i64 n, int d, const int *members, i64 nb, int bs, double tol,
+                                      u64 *out, hipStream_t s) {
+    return launch_simplex_common(P, n, 0, d, nullptr, nb, 1, tol, -1, 0, out, s, SxSel{members, bs, nullptr, d});
 }
 
 int launch_multi_simplex(const double *P, i64 n, i64 T, int d, const i64 *targets, i64 m, int relax,

@@ -29,6 +29,17 @@ def _positions(df: pd.DataFrame, labels) -> np.ndarray:
     return pos.astype(np.int64)
 
 
+def _require_unique_labels(df: pd.DataFrame) -> None:
+    """Curves are addressed by column label (:232,248).  With duplicated labels the reference's label tuples collapse
+    through a set (_helper.py:32) and `.loc` returns every column carrying a label, so bands silently merge curves, and
+    any target whose own label is duplicated -- hence the default `to_compute=None` -- dies with a TypeError inside
+    `_r2_containment` (tests/golden/g11_duplabels.json records this).  That accident is not reproduced: duplicated
+    labels are refused up front."""
+    if not df.columns.is_unique:
+        dup = list(df.columns[df.columns.duplicated()].unique())
+        raise ValueError(f'column labels must be unique to address curves; duplicated: {dup}')
+
+
 def _univariate_depths(df: pd.DataFrame, cols, J: int, relax: bool, device=None, algo='auto') -> np.ndarray:
     """Band depth of columns `cols` of `df` (rows = timepoints): sum_j S_nj / binom(n, j).
 
@@ -83,6 +94,7 @@ def _functionaldepth(data: List[pd.DataFrame], to_compute: Union[list, pd.Index]
         if cdef == 'simplex':
             cdef = 'r2'                                  # (:62-63)
         df = data[0]
+        _require_unique_labels(df)
         cols = df.columns if to_compute is None else to_compute     # (:68-71)
         if cdef == 'r2':
             depths = _univariate_depths(df, cols, J, relax, device=device, algo=algo)
@@ -124,6 +136,7 @@ def _samplefunctionaldepth(data: List[pd.DataFrame], K: int, to_compute: Union[l
         return pd.Series(dtype=np.float64)               # reference stub returns an empty list (:187-196)
 
     df = data[0]
+    _require_unique_labels(df)
     cols = df.columns if to_compute is None else to_compute
     orig = df.loc[:, cols]                               # (:161)
     ss = df.shape[1] // K                                # (:162)

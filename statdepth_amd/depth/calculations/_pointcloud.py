@@ -43,28 +43,50 @@ def _pointwisedepth(data: pd.DataFrame, to_compute: Union[list, pd.Index] = None
         raise ValueError(f'{containment} is not a valid containment measure. ')   # (:63-64)
 
 
+def _block_depths(P: np.ndarray, blocks, containment: str, device=None) -> np.ndarray:
+    """Depth of each block's target (its LAST row) inside the block, every block in one launch."""
+    width = max(len(b) for b in blocks)
+    mem = np.full((len(blocks), width), -1, dtype=np.int32)
+    for i, b in enumerate(blocks):
+        mem[i, :len(b)] = b
+    if containment == 'simplex':
+        d = P.shape[1]
+        sizes = np.array([len(b) for b in blocks], dtype=np.float64)
+        counts = engine.pointcloud_simplex_subset_counts(P, mem, device=device).astype(np.float64)
+        return counts / binom(sizes, d + 1)              # (:38,56) on the sample: its size INCLUDES the point
+    return engine.l1_subset_depth(P, mem, device=device)  # (:148-150) on the sample
+
+
 def _samplepointwisedepth(data: pd.DataFrame, to_compute: pd.Index = None, K=2, containment='simplex',
                           quiet=True, device=None) -> pd.Series:
     """K-block sampled point-cloud depth (:68-123).
 
-    Same sampling rule and RNG consumption as the reference: `ss = n // K` (:107) and,
-    per point, `ss` repetitions (:113 -- the loop bound is ss, not K) of a `data.sample(n=ss)`
-    draw (:114) with the point appended when missing (:117-118; the reference's
-    `DataFrame.append` no longer exists in pandas >= 2, `pd.concat` is its definition).
+    Same sampling rule and RNG consumption as the reference: `ss = n // K` (:107) and, per point, `ss`
+    repetitions (:113 -- the loop bound is ss, not K) of a `data.sample(n=ss)` draw (:114) with the point
+    appended when the draw missed it (:117-118; the reference's `DataFrame.append` is gone from pandas >= 2,
+    so the reference itself cannot run this path any more).  The draws are made first -- rows by position, from
+    the global numpy RNG exactly as `DataFrame.sample` consumes it -- and all len(to_compute) * ss
+    (point, sample) pairs are evaluated in ONE launch (sd_pointcloud_simplex_subset_counts /
+    sd_l1_subset_depth) instead of as many `_pointwisedepth` calls.
     """
     if K == 1:
         return _pointwisedepth(data=data, to_compute=to_compute, containment=containment, device=device)
+    if containment in ('mahalanobis', 'oja'):
+        raise NotImplementedError(f'{containment} depth is outside the band-depth hot path this engine covers')
+    if containment not in ('simplex', 'l1'):
+        raise ValueError(f'{containment} is not a valid containment measure. ')
     n, d = data.shape
-    depths = []
     if to_compute is None:
         to_compute = data.index
     ss = n // K
-    for time in to_compute:
-        cd = []
+    targets = _row_positions(data, to_compute)
+    if ss == 0 or len(targets) == 0:                     # the reference's mean over no draws
+        return pd.Series(index=to_compute, data=np.full(len(targets), np.nan))
+    rows = pd.Series(np.arange(n))                       # `.sample` on it draws what `data.sample(axis=0)` draws
+    blocks = []
+    for tp in targets:
         for _ in range(ss):
-            sdata = data.sample(n=ss, axis=0)
-            if time not in sdata.index:
-                sdata = pd.concat([sdata, data.loc[[time], :]])
-            cd.append(_pointwisedepth(data=sdata, to_compute=[time], containment=containment, device=device))
-        depths.append(np.mean(cd))
-    return pd.Series(index=to_compute, data=depths)
+            drawn = rows.sample(n=ss).to_numpy()
+            blocks.append(np.append(drawn[drawn != tp], tp))          # others in draw order, the point last
+    depth = _block_depths(data.to_numpy(dtype=np.float64), blocks, containment, device=device)
+    return pd.Series(index=to_compute, data=depth.reshape(len(targets), ss).mean(axis=1))

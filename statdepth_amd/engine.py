@@ -105,7 +105,8 @@ def mbd_counts(X, targets=None, J=2, algo="auto", device=None, return_tensor=Fal
         return out if return_tensor else out.cpu().numpy()
     wsb = lib.sd_mbd_workspace_bytes(M.T, M.n, M.st, M.sn, m, J, a)
     ws = t.empty(max(int(wsb), 8), dtype=t.uint8, device=dev)
-    check(lib.sd_mbd_counts(M.tensor.data_ptr(), M.T, M.n, M.st, M.sn, tp, m, J, a,
+    with t.cuda.device(dev):
+        check(lib.sd_mbd_counts(M.tensor.data_ptr(), M.T, M.n, M.st, M.sn, tp, m, J, a,
                             out.data_ptr(), ws.data_ptr(), wsb, _stream_ptr(dev)))
     if return_tensor:
         return out
@@ -120,9 +121,12 @@ def mbd_counts_range(X, target_begin, m, J=2, algo="auto", device=None, return_t
     dev = M.device
     a = ALGOS[algo] if isinstance(algo, str) else int(algo)
     out = t.empty((m, J - 1), dtype=t.int64, device=dev)
+    if m == 0:
+        return out if return_tensor else out.cpu().numpy()
     wsb = lib.sd_mbd_workspace_bytes(M.T, M.n, M.st, M.sn, m, J, a)
     ws = t.empty(max(int(wsb), 8), dtype=t.uint8, device=dev)
-    check(lib.sd_mbd_counts_range(M.tensor.data_ptr(), M.T, M.n, M.st, M.sn, int(target_begin), int(m), J, a,
+    with t.cuda.device(dev):
+        check(lib.sd_mbd_counts_range(M.tensor.data_ptr(), M.T, M.n, M.st, M.sn, int(target_begin), int(m), J, a,
                                   out.data_ptr(), ws.data_ptr(), wsb, _stream_ptr(dev)))
     if return_tensor:
         return out
@@ -143,7 +147,8 @@ def mbd_external_counts(X, Q, J=2, device=None):
     out = t.empty((m, J - 1), dtype=t.int64, device=dev)
     wsb = int(lib.sd_mbd_external_workspace_bytes(T, n, m, J)) + 1024
     ws = t.empty(wsb, dtype=t.uint8, device=dev)
-    check(lib.sd_mbd_external_counts(Xd.data_ptr(), T, n, Qd.data_ptr(), m, J, out.data_ptr(), ws.data_ptr(), wsb,
+    with t.cuda.device(dev):
+        check(lib.sd_mbd_external_counts(Xd.data_ptr(), T, n, Qd.data_ptr(), m, J, out.data_ptr(), ws.data_ptr(), wsb,
                                      _stream_ptr(dev)))
     return out.cpu().numpy()
 
@@ -166,7 +171,8 @@ def mbd_subset_counts(X, members, targets, J=2, device=None):
     if nb == 0:
         return out.cpu().numpy()
     md, td = t.from_numpy(mem).to(dev), t.from_numpy(tg).to(dev)
-    check(lib.sd_mbd_subset_counts(Xd.data_ptr(), T, n, md.data_ptr(), nb, bs, td.data_ptr(), J, out.data_ptr(),
+    with t.cuda.device(dev):
+        check(lib.sd_mbd_subset_counts(Xd.data_ptr(), T, n, md.data_ptr(), nb, bs, td.data_ptr(), J, out.data_ptr(),
                                    _stream_ptr(dev)))
     return out.cpu().numpy()
 
@@ -181,7 +187,8 @@ def above_below(X, targets=None, device=None):
     out = t.empty((m, M.T, 2), dtype=t.int32, device=dev)
     wsb = M.T * M.n * 8 + 1024
     ws = t.empty(wsb, dtype=t.uint8, device=dev)
-    check(lib.sd_above_below(M.tensor.data_ptr(), M.T, M.n, M.st, M.sn, tp, m, out.data_ptr(),
+    with t.cuda.device(dev):
+        check(lib.sd_above_below(M.tensor.data_ptr(), M.T, M.n, M.st, M.sn, tp, m, out.data_ptr(),
                              ws.data_ptr(), wsb, _stream_ptr(dev)))
     return out.cpu().numpy().astype(np.int64) & 0xFFFFFFFF
 
@@ -198,7 +205,8 @@ def bd_strict_counts(X, targets=None, J=2, device=None):
         return out.cpu().numpy()
     wsb = lib.sd_bd_strict_j_workspace_bytes(M.T, M.n, M.st, M.sn, m, J)
     ws = t.empty(max(int(wsb), 8), dtype=t.uint8, device=dev)
-    check(lib.sd_bd_strict_j_counts(M.tensor.data_ptr(), M.T, M.n, M.st, M.sn, tp, m, J,
+    with t.cuda.device(dev):
+        check(lib.sd_bd_strict_j_counts(M.tensor.data_ptr(), M.T, M.n, M.st, M.sn, tp, m, J,
                                     out.data_ptr(), ws.data_ptr(), wsb, _stream_ptr(dev)))
     return out.cpu().numpy()
 
@@ -225,7 +233,8 @@ def l1_depth(P, targets=None, device=None):
     out = t.empty(m, dtype=t.float64, device=dev)
     if m == 0:
         return out.cpu().numpy()
-    check(lib.sd_l1_depth(Pd.data_ptr(), n, d, tp, m, out.data_ptr(), _stream_ptr(dev)))
+    with t.cuda.device(dev):
+        check(lib.sd_l1_depth(Pd.data_ptr(), n, d, tp, m, out.data_ptr(), _stream_ptr(dev)))
     return out.cpu().numpy()
 
 
@@ -239,9 +248,11 @@ def pointcloud_simplex_counts(P, targets=None, tol=1e-7, samples=None, seed=0, d
     if m == 0:
         return out.cpu().numpy()
     if samples is None:
-        check(lib.sd_pointcloud_simplex_counts(Pd.data_ptr(), n, d, tp, m, tol, out.data_ptr(), _stream_ptr(dev)))
+        with t.cuda.device(dev):
+            check(lib.sd_pointcloud_simplex_counts(Pd.data_ptr(), n, d, tp, m, tol, out.data_ptr(), _stream_ptr(dev)))
     else:
-        check(lib.sd_pointcloud_simplex_sampled(Pd.data_ptr(), n, d, tp, m, tol, int(samples), int(seed),
+        with t.cuda.device(dev):
+            check(lib.sd_pointcloud_simplex_sampled(Pd.data_ptr(), n, d, tp, m, tol, int(samples), int(seed),
                                                 out.data_ptr(), _stream_ptr(dev)))
     return out.cpu().numpy()
 
@@ -257,9 +268,88 @@ def multi_simplex_counts(P, targets=None, relax=True, tol=1e-7, samples=None, se
     if m == 0:
         return out.cpu().numpy()
     if samples is None:
-        check(lib.sd_multi_simplex_counts(Pd.data_ptr(), n, T, d, tp, m, int(bool(relax)), tol,
+        with t.cuda.device(dev):
+            check(lib.sd_multi_simplex_counts(Pd.data_ptr(), n, T, d, tp, m, int(bool(relax)), tol,
                                           out.data_ptr(), _stream_ptr(dev)))
     else:
-        check(lib.sd_multi_simplex_sampled(Pd.data_ptr(), n, T, d, tp, m, int(bool(relax)), tol, int(samples),
+        with t.cuda.device(dev):
+            check(lib.sd_multi_simplex_sampled(Pd.data_ptr(), n, T, d, tp, m, int(bool(relax)), tol, int(samples),
                                            int(seed), out.data_ptr(), _stream_ptr(dev)))
+    return out.cpu().numpy()
+
+
+def _members_dev(members, dev):
+    t = torch()
+    mem = np.ascontiguousarray(np.asarray(members, dtype=np.int32))
+    if mem.ndim != 2:
+        raise ValueError("members must be 2-D (blocks x block size, -1 padded, target last)")
+    return t.from_numpy(mem).to(dev), mem.shape[0], mem.shape[1]
+
+
+def pointcloud_simplex_external_counts(P, Q, tol=1e-7, device=None):
+    """int64[m]: (d+1)-subsets of ALL rows of P whose simplex contains the external point Q[q]."""
+    t = torch()
+    lib = _native.require_device()
+    Pd, dev = _points_dev(P, 2, device)
+    Qd, _ = _points_dev(Q, 2, dev)
+    n, d = Pd.shape
+    if Qd.shape[1] != d:
+        raise ValueError("Q must have the same number of coordinates as P")
+    m = Qd.shape[0]
+    out = t.empty(m, dtype=t.int64, device=dev)
+    if m == 0:
+        return out.cpu().numpy()
+    with t.cuda.device(dev):
+        check(lib.sd_pointcloud_simplex_external_counts(Pd.data_ptr(), n, d, Qd.data_ptr(), m, tol, out.data_ptr(),
+                                                        _stream_ptr(dev)))
+    return out.cpu().numpy()
+
+
+def pointcloud_simplex_subset_counts(P, members, tol=1e-7, device=None):
+    """int64[nb]: per block (rows of `members`, -1 padded, others first, target last) the (d+1)-subsets of the
+    block's others whose simplex contains its target."""
+    t = torch()
+    lib = _native.require_device()
+    Pd, dev = _points_dev(P, 2, device)
+    n, d = Pd.shape
+    md, nb, bs = _members_dev(members, dev)
+    out = t.empty(nb, dtype=t.int64, device=dev)
+    if nb == 0:
+        return out.cpu().numpy()
+    with t.cuda.device(dev):
+        check(lib.sd_pointcloud_simplex_subset_counts(Pd.data_ptr(), n, d, md.data_ptr(), nb, bs, tol, out.data_ptr(),
+                                                      _stream_ptr(dev)))
+    return out.cpu().numpy()
+
+
+def l1_external_depth(P, Q, device=None):
+    """float64[m]: L1 depth of the external point Q[q] inside P u {Q[q]}."""
+    t = torch()
+    lib = _native.require_device()
+    Pd, dev = _points_dev(P, 2, device)
+    Qd, _ = _points_dev(Q, 2, dev)
+    n, d = Pd.shape
+    if Qd.shape[1] != d:
+        raise ValueError("Q must have the same number of coordinates as P")
+    m = Qd.shape[0]
+    out = t.empty(m, dtype=t.float64, device=dev)
+    if m == 0:
+        return out.cpu().numpy()
+    with t.cuda.device(dev):
+        check(lib.sd_l1_external_depth(Pd.data_ptr(), n, d, Qd.data_ptr(), m, out.data_ptr(), _stream_ptr(dev)))
+    return out.cpu().numpy()
+
+
+def l1_subset_depth(P, members, device=None):
+    """float64[nb]: L1 depth of each block's target (last row of the block) inside the block."""
+    t = torch()
+    lib = _native.require_device()
+    Pd, dev = _points_dev(P, 2, device)
+    n, d = Pd.shape
+    md, nb, bs = _members_dev(members, dev)
+    out = t.empty(nb, dtype=t.float64, device=dev)
+    if nb == 0:
+        return out.cpu().numpy()
+    with t.cuda.device(dev):
+        check(lib.sd_l1_subset_depth(Pd.data_ptr(), n, d, md.data_ptr(), nb, bs, out.data_ptr(), _stream_ptr(dev)))
     return out.cpu().numpy()

@@ -82,6 +82,25 @@ def _depths_of_external(F: pd.DataFrame, Gcols: pd.DataFrame, J: int, relax: boo
     return depth
 
 
+def _fresh_label(frame_labels, stem):
+    """A label no column / row of the frame carries: the temporary name g travels under inside F."""
+    taken = set(frame_labels)
+    label, k = stem, 0
+    while label in taken:
+        k += 1
+        label = f'{stem}_{k}'
+    return label
+
+
+def _depth_of_one_external(Fd: pd.DataFrame, g: np.ndarray, kw) -> float:
+    """FunctionalDepth(F u {g}, to_compute=[g]) with g under a label of its own (never one of F's: the reference's
+    `F.loc[:, col] = G.loc[:, col]` (:126) overwrites F's curve when the samples share labels)."""
+    lab = _fresh_label(Fd.columns, 'g_external')
+    Fg = Fd.copy()
+    Fg.loc[:, lab] = g
+    return FunctionalDepth([Fg], to_compute=[lab], **kw).loc[lab]
+
+
 def _functionalhomogeneity(F: List[pd.DataFrame], G: List[pd.DataFrame], K=None, J=2, containment='r2', method='p1',
                            relax=False, deep_check=False, quiet=False):
     _handle_errors(F, G, method)
@@ -93,13 +112,13 @@ def _functionalhomogeneity(F: List[pd.DataFrame], G: List[pd.DataFrame], K=None,
         if 'g_deepest' in Fd.columns:
             Fd = Fd.drop('g_deepest', axis=1)
         G_deepest = G_depths.get_deepest_data(n=1)          # (:95)
+        # every g is evaluated inside the intact F u {g} (n_F + 1 curves), batched or not: one semantics for both
         batched = (K is None and containment == 'r2' and relax)
         if batched:
-            G_deep_in_F = pd.Series(index=['g_deepest'], data=_depths_of_external(Fd, G_deepest, J, relax))
+            deep = _depths_of_external(Fd, G_deepest, J, relax)
         else:
-            Fg = Fd.copy()
-            Fg.loc[:, 'g_deepest'] = G_deepest.iloc[:, 0].to_numpy()     # (:101)
-            G_deep_in_F = FunctionalDepth([Fg], to_compute=['g_deepest'], **kw)
+            deep = [_depth_of_one_external(Fd, G_deepest.iloc[:, 0].to_numpy(), kw)]
+        G_deep_in_F = pd.Series(index=['g_deepest'], data=deep)
         if method == 'p1':
             return G_deep_in_F
         elif method == 'p2':
@@ -107,14 +126,9 @@ def _functionalhomogeneity(F: List[pd.DataFrame], G: List[pd.DataFrame], K=None,
             return np.abs(G_deep_in_F - F_depths.median().iloc[0])       # (:120)
         elif method == 'p3':
             if batched:
-                t = _depths_of_external(Fd, Gd, J, relax)
+                t = _depths_of_external(Fd, Gd, J, relax)    # (:125-128) for all of G in one launch
             else:
-                t = []
-                for col in Gd.columns:                      # (:125-128)
-                    Fg = Fd.copy()
-                    Fg.loc[:, col] = Gd.loc[:, col].to_numpy()
-                    t.append(FunctionalDepth([Fg], to_compute=[col], K=K, J=J, containment=containment, relax=relax,
-                                             deep_check=deep_check).loc[col])
+                t = [_depth_of_one_external(Fd, Gd.iloc[:, c].to_numpy(), kw) for c in range(Gd.shape[1])]
             depths_G_in_F = pd.Series(index=list(Gd.columns), data=t).sort_values(ascending=False)
             return depths_G_in_F.iloc[0] / G_depths.median().iloc[0]      # (:133)
         elif method == 'p4':
@@ -139,51 +153,79 @@ def _functionalhomogeneity(F: List[pd.DataFrame], G: List[pd.DataFrame], K=None,
                              f'Use one of [\'p1\', \'p2\', \'p3\', \'p4\']')
 
 
+# ---- point clouds (:155-200) -------------------------------------------------------------------------------------
+# The reference appends one point of G to F, asks for that point's depth, and drops it again -- once for G's deepest
+# point and, for P3, once per point of G.  Here the points of G are EXTERNAL targets of one launch against F
+# (sd_pointcloud_simplex_external_counts / sd_l1_external_depth); the sample the depth refers to is F u {g}
+# (n_F + 1 points), as in the reference's temporary frame.  With K (block sampling) the estimator draws from the
+# global RNG per call, so the calls stay separate -- each is itself one launch (_samplepointwisedepth).
+def _external_point_depths(F: pd.DataFrame, pts: pd.DataFrame, K, containment) -> np.ndarray:
+    if K is not None:
+        out = []
+        for r in range(pts.shape[0]):
+            lab = _fresh_label(F.index, 'g_external')
+            Fg = pd.concat([F, pts.iloc[[r], :].set_axis([lab], axis=0)])
+            out.append(PointcloudDepth(Fg, to_compute=[lab], K=K, containment=containment).loc[lab])
+        return np.asarray(out, dtype=np.float64)
+    Fx, Qx = F.to_numpy(dtype=np.float64), pts.to_numpy(dtype=np.float64)
+    n, d = Fx.shape
+    if containment == 'simplex':
+        return engine.pointcloud_simplex_external_counts(Fx, Qx).astype(np.float64) / binom(n + 1, d + 1)
+    if containment == 'l1':
+        return engine.l1_external_depth(Fx, Qx)
+    if containment in ('mahalanobis', 'oja'):
+        raise NotImplementedError(f'{containment} depth is outside the band-depth hot path this engine covers')
+    raise ValueError(f'{containment} is not a valid containment measure. ')
+
+
 def _pointcloudhomogeneity(F: pd.DataFrame, G: pd.DataFrame, K=None, containment='simplex', method='p1'):
-    _handle_errors(F, G, method)
-    G_depths = PointcloudDepth(data=G, K=K, containment=containment)
-    F_depths = PointcloudDepth(data=F, K=K, containment=containment)
-    hom = 0
-    G_deepest = G_depths.get_deepest_data(n=1).copy()
-    G_deepest.index = ['g_deepest']
-    # the reference uses DataFrame.append (:173), gone in pandas >= 2; pd.concat is its definition
-    Fg = pd.concat([F, G_deepest])
-    G_deep_in_F = PointcloudDepth(Fg, to_compute=['g_deepest'], K=K, containment=containment).ordered().loc['g_deepest']
-    if method == 'p1':
-        hom = G_deep_in_F / F_depths.median().iloc[0]
-    elif method == 'p2':
-        hom = 1 - np.abs(G_deep_in_F - F_depths.median().iloc[0])
-    elif method == 'p3':
-        t = []
-        for point in G.index:                               # (:183-186)
-            Fp = F.copy()
-            Fp.loc[point, :] = G.loc[point, :]
-            t.append(PointcloudDepth(Fp, to_compute=[point], K=K, containment=containment).loc[point])
-        depths_G_in_F = pd.Series(index=list(G.index), data=t).sort_values(ascending=False)
-        hom = depths_G_in_F.iloc[0] / G_depths.median().iloc[0]
-    elif method == 'p4':
-        t1 = np.abs(_pointcloudhomogeneity(F, G, K, containment, 'p3')[2] - _pointcloudhomogeneity(F, F, K, containment, 'p1')[2])
-        t2 = np.abs(_pointcloudhomogeneity(F, G, K, containment, 'p3')[2] - _pointcloudhomogeneity(G, G, K, containment, 'p1')[2])
-        hom = t1 * t2
-    else:
+    if method not in ('p1', 'p2', 'p3', 'p4'):
         raise ValueError(f'{method} is not a valid depth method for the given data. '
                          f'Use one of [\'p1\', \'p2\', \'p3\', \'p4\']')
+    _handle_errors(F, G, method)
+    depth_of = lambda sample: PointcloudDepth(data=sample, K=K, containment=containment)      # noqa: E731
+    F_depths, G_depths = depth_of(F), depth_of(G)
+
+    def deepest_in(sample_depths, host):                   # depth of a sample's deepest point inside host u {point}
+        return _external_point_depths(host, sample_depths.get_deepest_data(n=1), K, containment)[0]
+
+    def p3():                                              # best depth any point of G reaches inside F, over G's median
+        return _external_point_depths(F, G, K, containment).max() / G_depths.median().iloc[0]
+
+    if method == 'p1':
+        hom = deepest_in(G_depths, F) / F_depths.median().iloc[0]
+    elif method == 'p2':
+        hom = 1 - np.abs(deepest_in(G_depths, F) - F_depths.median().iloc[0])
+    elif method == 'p3':
+        hom = p3()
+    else:                                                  # p4: |p3 - p1(F,F)| * |p3 - p1(G,G)| (:189-192)
+        v = p3()
+        p1_FF = deepest_in(F_depths, F) / F_depths.median().iloc[0]
+        p1_GG = deepest_in(G_depths, G) / G_depths.median().iloc[0]
+        hom = np.abs(v - p1_FF) * np.abs(v - p1_GG)
     return F_depths, G_depths, hom
 
 
-def P1_homogeneity(F: pd.DataFrame, G: pd.DataFrame, K=None, J=2, containment='r2', relax=False, quiet=False) -> float:
-    '''P1 coefficient (:214-260): depth of G's deepest curve inside F.'''
-    G_depth = FunctionalDepth(data=[G], K=K, J=J, containment=containment, relax=relax, quiet=quiet)
-    G_deepest = G_depth.get_deepest_data()
+def _with_g_deepest(F: pd.DataFrame, G: pd.DataFrame, kw) -> pd.DataFrame:
+    G_deepest = FunctionalDepth(data=[G], **kw).get_deepest_data()
     Fg = F.copy()
-    Fg.loc[:, 'G_deepest'] = G_deepest.iloc[:, 0].to_numpy()
-    G_deep_in_F = FunctionalDepth([Fg], to_compute=['G_deepest'], K=K, J=J, containment=containment, relax=relax,
-                                  quiet=quiet)
-    return G_deep_in_F.iloc[0]
+    Fg.loc[:, 'G_deepest'] = G_deepest.iloc[:, 0].to_numpy()          # (:244)
+    return Fg
+
+
+def P1_homogeneity(F: pd.DataFrame, G: pd.DataFrame, K=None, J=2, containment='r2', relax=False, quiet=False) -> float:
+    '''P1 coefficient (:214-260): depth of G's deepest curve inside F u {that curve}.'''
+    kw = dict(K=K, J=J, containment=containment, relax=relax, quiet=quiet)
+    return FunctionalDepth([_with_g_deepest(F, G, kw)], to_compute=['G_deepest'], **kw).iloc[0]
 
 
 def P2_homogeneity(F: pd.DataFrame, G: pd.DataFrame, K=None, J=2, containment='r2', relax=False, quiet=False) -> float:
-    '''P2 coefficient (:262-306): |P1(F,G) - depth of F's own deepest curve|.'''
-    P1_F_G = P1_homogeneity(F=F, G=G, K=K, J=J, containment=containment, relax=relax, quiet=quiet)
-    P1_F_F = FunctionalDepth(data=[F], K=K, J=J, containment=containment, relax=relax, quiet=quiet).deepest().iloc[0]
+    '''P2 coefficient (:262-306): |P1(F,G) - deepest depth of F|.
+
+    The reference's P1 leaves its 'G_deepest' column in the caller's F (:244), so the second term is the deepest
+    depth of F WITH that column (:297-304).  The value is reproduced; the caller's frame is left alone.'''
+    kw = dict(K=K, J=J, containment=containment, relax=relax, quiet=quiet)
+    Fg = _with_g_deepest(F, G, kw)
+    P1_F_G = FunctionalDepth([Fg], to_compute=['G_deepest'], **kw).iloc[0]
+    P1_F_F = FunctionalDepth(data=[Fg], **kw).deepest().iloc[0]
     return np.abs(P1_F_G - P1_F_F)

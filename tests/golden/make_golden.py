@@ -351,6 +351,66 @@ def build_cases():
     for m in ("p1", "p2", "p3"):
         add(lambda name, m=m: homog_case(name, m), f"h_{m}")
 
+    # the function forms P1_homogeneity / P2_homogeneity (homogeneity.py:214-306).  NB the reference's P1 leaves its
+    # 'G_deepest' column in the caller's F, and P2 then takes F's deepest depth WITH that column present.
+    def homog_fn_case(name, which, relax):
+        if REF not in sys.path:
+            sys.path.insert(0, REF)
+        from statdepth.homogeneity import P1_homogeneity, P2_homogeneity
+        rng = np.random.default_rng(51)
+        F = pd.DataFrame(rng.normal(size=(9, 8)).cumsum(axis=0), columns=[f"F{i}" for i in range(8)])
+        G = pd.DataFrame(rng.normal(size=(9, 6)).cumsum(axis=0) + 0.4, columns=[f"G{i}" for i in range(6)])
+        t0 = time.time()
+        fn = P1_homogeneity if which == "P1" else P2_homogeneity
+        val = fn(F.copy(), G.copy(), relax=relax, quiet=True)
+        return {"name": name, "kind": "homogeneity_fn", "ref": "homogeneity.py:214-306",
+                "call": {"fn": which, "relax": relax, "J": 2},
+                "input": {"F": _frame_json(F), "G": _frame_json(G)},
+                "value": [_enc(float(val))], "elapsed_s": time.time() - t0}
+    for which in ("P1", "P2"):
+        for relax in (True, False):
+            add(lambda name, which=which, relax=relax: homog_fn_case(name, which, relax),
+                f"h_{which}fn_{'relax' if relax else 'strict'}")
+
+    # P3 with OVERLAPPING labels (the default RangeIndex case): the reference's loop overwrites F's own column with
+    # g and then drops it (homogeneity.py:125-128), so F shrinks as the loop runs.  Recorded for documentation: the
+    # build deliberately evaluates every g inside the intact F u {g} instead (tests/test_hip_parity.py).
+    def homog_overlap_case(name):
+        if REF not in sys.path:
+            sys.path.insert(0, REF)
+        from statdepth.homogeneity import FunctionalHomogeneity
+        rng = np.random.default_rng(52)
+        F = pd.DataFrame(rng.normal(size=(8, 7)).cumsum(axis=0))
+        G = pd.DataFrame(rng.normal(size=(8, 5)).cumsum(axis=0) + 0.3)
+        t0 = time.time()
+        val = FunctionalHomogeneity([F.copy()], [G.copy()], method="p3", relax=True, quiet=True).homogeneity()
+        return {"name": name, "kind": "homogeneity_overlap", "ref": "homogeneity.py:125-133",
+                "call": {"method": "p3", "relax": True, "J": 2},
+                "input": {"F": _frame_json(F), "G": _frame_json(G)},
+                "reference_value": [_enc(v) for v in np.asarray(val, dtype=float).ravel()],
+                "elapsed_s": time.time() - t0}
+    add(homog_overlap_case, "h_p3_overlap")
+
+    # duplicate column labels: _subsequences collapses label tuples through a set (_helper.py:32) and `.loc` with a
+    # duplicated label returns every column carrying it.  What the reference does, recorded per call.
+    def duplabel_case(name):
+        ref = _ref()
+        rng = np.random.default_rng(3)
+        X = np.round(rng.normal(size=(6, 5)).cumsum(axis=0), 1)
+        df = pd.DataFrame(X, columns=["a", "b", "b", "c", "d"])
+        t0 = time.time()
+        calls = []
+        for relax in (True, False):
+            for tc in (["a"], ["c", "d"], ["b"], None):
+                try:
+                    r = ref["FunctionalDepth"]([df.copy()], to_compute=tc, relax=relax)
+                    calls.append({"relax": relax, "to_compute": tc, "depths": [_enc(v) for v in r.to_numpy()]})
+                except Exception as e:          # noqa: BLE001 -- the exception type is the recorded behaviour
+                    calls.append({"relax": relax, "to_compute": tc, "raises": type(e).__name__})
+        return {"name": name, "kind": "duplabels", "ref": "_helper.py:32, _functional.py:232-248",
+                "input": _frame_json(df), "calls": calls, "elapsed_s": time.time() - t0}
+    add(duplabel_case, "g11_duplabels")
+
     return cases
 
 

@@ -649,3 +649,280 @@ def test_big_n_routes(eng, oracle, monkeypatch):
     monkeypatch.delenv("SD_BIG_IMPL")
     tg = np.array([0, 29999, 12345, 7])
     assert (eng.mbd_counts(X, tg, 3, algo="rank") == oracle.mbd_counts(X, tg, 3)).all()
+
+
+# ---------------------------------------------------------------- simplex containment, d = 5..8 (config 4's kernels)
+def _simplex_cloud(rng, n, d, kind):
+    """Point sets for the register-resident simplex kernels: generic position, a hyperplane (every simplex rank
+    deficient -> the "undecided" hand-off to the generic code), and a mix with repeated points."""
+    P = rng.normal(size=(n, d))
+    if kind == "flat":
+        P[:, d - 1] = 0.25                                   # all points in one hyperplane
+    elif kind == "mixed":
+        P[: n // 2, d - 1] = 0.0                             # half the cloud in a hyperplane
+        P[1] = P[0]                                          # a repeated point
+        P[n - 1] = 0.5 * (P[2] + P[3])                       # a point on a segment between two others
+    return P
+
+
+@pytest.mark.parametrize("d", [5, 6, 7, 8])
+def test_simplex_high_d_exhaustive_vs_oracle(eng, oracle, monkeypatch, d):
+    """simplex_kernel_fast<5..8> (BASELINE config 4's d = 8 instantiation among them): exhaustive enumeration at small
+    n against the oracle and against the generic kernel, for point clouds and for multivariate curves."""
+    rng = np.random.default_rng(100 + d)
+    n = d + 4                                                # C(n-1, d+1) = C(d+3, 2) subsets per target
+    for kind in ("generic", "flat", "mixed"):
+        P = _simplex_cloud(rng, n, d, kind)
+        want = oracle.pointcloud_simplex_counts(P)
+        got = eng.pointcloud_simplex_counts(P)
+        assert (got == want).all(), (d, kind)
+        monkeypatch.setenv("SD_SIMPLEX_GENERIC", "1")
+        assert (eng.pointcloud_simplex_counts(P) == want).all(), (d, kind, "generic kernel")
+        monkeypatch.delenv("SD_SIMPLEX_GENERIC")
+        if kind == "generic":
+            assert want.sum() > 0
+    # a cloud whose centre is deep: the counts are not all zero in high dimension
+    Q = rng.normal(size=(n, d))
+    Q[0] = Q[1:].mean(axis=0)
+    want = oracle.pointcloud_simplex_counts(Q)
+    assert want[0] > 0 and (eng.pointcloud_simplex_counts(Q) == want).all()
+    C = rng.normal(size=(d + 3, 4, d)).cumsum(axis=1)
+    C[0] = C[1:].mean(axis=0)
+    C[2, :, d - 1] = C[3, :, d - 1]                          # two curves agree in one feature
+    for relax in (True, False):
+        want = oracle.multi_simplex_counts(C, None, relax)
+        assert (eng.multi_simplex_counts(C, None, relax) == want).all(), (d, relax)
+    tg = np.array([d + 2, 0, 3])
+    assert (eng.multi_simplex_counts(C, tg, True) == oracle.multi_simplex_counts(C, tg, True)).all()
+
+
+@pytest.mark.parametrize("d", [5, 6, 7, 8])
+def test_simplex_high_d_sampled_vs_oracle(eng, oracle, monkeypatch, d):
+    """The seeded subset sampler at d = 5..8, kernel == CPU restatement draw for draw (fast and generic kernels)."""
+    rng = np.random.default_rng(200 + d)
+    P = rng.normal(size=(60, d)) * rng.uniform(0.5, 2.0, size=d)
+    P[:5] *= 0.05                                            # deep points: non-zero counts
+    want = oracle.simplex_sampled(P, samples=400, seed=d)
+    assert want[:5].sum() > 0
+    assert (eng.pointcloud_simplex_counts(P, samples=400, seed=d) == want).all()
+    C = rng.normal(size=(40, 12, d)).cumsum(axis=1)
+    C[:4] *= 0.05
+    tg = np.array([0, 1, 2, 3, 17, 39])
+    for relax in (True, False):
+        want = oracle.simplex_sampled(C, tg, relax=relax, samples=200, seed=11)
+        assert (eng.multi_simplex_counts(C, tg, relax=relax, samples=200, seed=11) == want).all(), (d, relax)
+    monkeypatch.setenv("SD_SIMPLEX_GENERIC", "1")
+    want = oracle.simplex_sampled(C, tg, relax=True, samples=200, seed=11)
+    assert (eng.multi_simplex_counts(C, tg, relax=True, samples=200, seed=11) == want).all()
+    monkeypatch.delenv("SD_SIMPLEX_GENERIC")
+    assert want[:4].sum() > 0
+
+
+def test_config4_full_size(eng, oracle):
+    """BASELINE.json configs[3]: 5 000 multivariate curves (d = 8) x 500 timepoints, seeded sampled simplicial depth with
+    S = 4 096 subsets per target: the oracle on 8 targets, determinism, and independence
+    of the way the targets are split over calls (what sharding over GPUs relies on)."""
+    import torch
+    n, T, d, S, seed = 5000, 500, 8, 4096, 1236
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    P = torch.randn(n, T, d, dtype=torch.float64, device="cuda", generator=g).cumsum(1)
+    P[:16] *= 0.02                                           # a few central curves: counts that are not all zero
+    full = eng.multi_simplex_counts(P, None, relax=True, samples=S, seed=seed)
+    assert full.shape == (n,) and full.min() >= 0 and full.max() <= S * T
+    assert full[:16].sum() > 0
+    tg = np.array([0, 3, 15, 16, 777, 2500, 4998, 4999])
+    Ph = P.cpu().numpy()
+    want = oracle.simplex_sampled(Ph, tg, relax=True, samples=S, seed=seed)
+    assert (full[tg] == want).all()
+    # split-independence: any block of targets computed on its own gives the rows of the full call
+    for lo, hi in ((0, 625), (4375, 5000)):
+        blk = eng.multi_simplex_counts(P, np.arange(lo, hi), relax=True, samples=S, seed=seed)
+        assert (blk == full[lo:hi]).all()
+    # strict form (c // T) on the central curves
+    tgs = np.arange(0, 24)
+    strict = eng.multi_simplex_counts(P, tgs, relax=False, samples=S, seed=seed)
+    assert (strict[:8] == oracle.simplex_sampled(Ph, tgs[:8], relax=False, samples=S, seed=seed)).all()
+    assert (strict <= full[tgs] // T).all()
+    # the estimator through the public API shape: depth in [0, 1]
+    depth = full.astype(np.float64) / T / S
+    assert depth.max() <= 1.0
+
+
+def test_config5_full_size_simplex_and_l1(eng, oracle):
+    """BASELINE.json configs[4]: 10^6 points in R^3 -- sampled simplicial depth (R = 4 096 tetrahedra per point) and L1
+    depth at full size, the oracle on a sample of targets (the L-infinity form is test_million_points_linf_shape)."""
+    rng = np.random.default_rng(1237)
+    n, R = 1_000_000, 4096
+    P = rng.normal(size=(n, 3))
+    tg = np.concatenate([np.arange(8), rng.integers(0, n, size=180), [n - 1]])
+    got = eng.pointcloud_simplex_counts(P, samples=R, seed=1237)
+    assert got.shape == (n,) and got.max() <= R
+    want = oracle.simplex_sampled(P, tg, samples=R, seed=1237)
+    assert (got[tg] == want).all()
+    # central points are deep, far points are not: the estimate orders them like the distance from the origin
+    r = np.linalg.norm(P, axis=1)
+    assert got[r < 0.3].mean() > 4 * got[r > 2.5].mean()
+    again = eng.pointcloud_simplex_counts(P, tg, samples=R, seed=1237)
+    assert (again == want).all()
+    l1 = eng.l1_depth(P)
+    tl = tg[:64]
+    assert_depths_close(l1[tl], oracle.l1_depth(P, tl), TOL)
+    assert l1.min() >= 0.0 and l1.max() <= 1.0 and l1[np.argmin(r)] > 0.9
+
+
+# ---------------------------------------------------------------- external targets / explicit blocks of points
+def test_pointcloud_external_and_subsets_vs_oracle(eng, oracle):
+    rng = np.random.default_rng(17)
+    for (n, d, m) in [(14, 2, 9), (11, 3, 5), (9, 5, 4), (30, 1, 7)]:
+        F = rng.normal(size=(n, d))
+        G = rng.normal(size=(m, d)) * 0.5
+        G[0] = F[0]                                          # an external point equal to a sample point
+        cnt = eng.pointcloud_simplex_external_counts(F, G)
+        l1 = eng.l1_external_depth(F, G)
+        for q in range(m):
+            Fg = np.concatenate([F, G[q:q + 1]])
+            assert cnt[q] == oracle.pointcloud_simplex_counts(Fg, [n])[0], (n, d, q)
+            assert_depths_close(l1[q:q + 1], oracle.l1_depth(Fg, [n]), TOL)
+        # explicit blocks: others first, target last, ragged sizes
+        blocks = []
+        for k in range(25):
+            size = int(rng.integers(d + 2, n + 1))
+            blocks.append(rng.choice(n, size=size, replace=False))
+        width = max(len(b) for b in blocks)
+        M = np.full((len(blocks), width), -1, dtype=np.int32)
+        for i, b in enumerate(blocks):
+            M[i, :len(b)] = b
+        cnt = eng.pointcloud_simplex_subset_counts(F, M)
+        l1 = eng.l1_subset_depth(F, M)
+        for i, b in enumerate(blocks):
+            sub = F[b]
+            assert cnt[i] == oracle.pointcloud_simplex_counts(sub, [len(b) - 1])[0], (n, d, i)
+            assert_depths_close(l1[i:i + 1], oracle.l1_depth(sub, [len(b) - 1]), TOL)
+
+
+@pytest.mark.parametrize("containment", ["simplex", "l1"])
+def test_pointcloud_ksampled_vs_restatement(oracle, containment):
+    """PointcloudDepth(K=...) (_samplepointwisedepth, _pointcloud.py:68-123; the reference itself cannot run it on
+    pandas >= 2): the batched launch against a CPU restatement of the same draw sequence -- per point, ss = n // K
+    draws of `data.sample(n=ss)`, the point appended when missed, exact depth inside the sample, mean."""
+    from statdepth_amd import PointcloudDepth
+    rng = np.random.default_rng(23)
+    n, d, K = 26, 2, 3
+    df = pd.DataFrame(rng.normal(size=(n, d)), index=[f"p{i}" for i in range(n)], columns=["x", "y"])
+    tc = ["p3", "p0", "p25", "p11"]
+    np.random.seed(99)
+    got = PointcloudDepth(df, to_compute=tc, K=K, containment=containment)
+    assert list(got.index) == tc
+    np.random.seed(99)
+    ss = n // K
+    want = []
+    for lab in tc:
+        vals = []
+        for _ in range(ss):
+            sdata = df.sample(n=ss, axis=0)
+            if lab not in sdata.index:
+                sdata = pd.concat([sdata, df.loc[[lab], :]])
+            pos = list(sdata.index).index(lab)
+            if containment == "simplex":
+                vals.append(oracle.pointcloud_depths(sdata.to_numpy(), [pos])[0])
+            else:
+                vals.append(oracle.l1_depth(sdata.to_numpy(), [pos])[0])
+        want.append(np.mean(vals))
+    assert_depths_close(got.to_numpy(), np.array(want), TOL)
+    # every point (to_compute=None), K = 1 falls through to the exact depth
+    np.random.seed(5)
+    allp = PointcloudDepth(df, K=2, containment=containment)
+    assert list(allp.index) == list(df.index) and np.isfinite(allp.to_numpy()).all()
+    exact = PointcloudDepth(df, K=1, containment=containment)
+    assert_depths_close(exact.to_numpy(), PointcloudDepth(df, containment=containment).to_numpy(), TOL)
+
+
+# ---------------------------------------------------------------- homogeneity entry points
+@pytest.mark.parametrize("name", golden_names(kind="homogeneity_fn"))
+def test_golden_homogeneity_functions(name):
+    """P1_homogeneity / P2_homogeneity (homogeneity.py:214-306) equal the reference's values, including P2's second term
+    taken over F WITH the 'G_deepest' column the reference's P1 leaves behind; the caller's frames are not touched."""
+    from statdepth_amd.homogeneity.homogeneity import P1_homogeneity, P2_homogeneity
+    fx = load_golden(name)
+    F, G = frame_df(fx["input"]["F"]), frame_df(fx["input"]["G"])
+    Fc, Gc = F.copy(), G.copy()
+    fn = P1_homogeneity if fx["call"]["fn"] == "P1" else P2_homogeneity
+    got = fn(F, G, relax=fx["call"]["relax"], quiet=True)
+    assert_depths_close(np.array([got], dtype=float), np.array(fx["value"], dtype=float), TOL)
+    assert F.equals(Fc) and G.equals(Gc)
+
+
+@pytest.mark.parametrize("relax", [True, False])
+def test_homogeneity_p3_overlapping_labels(oracle, relax):
+    """P3 with the default integer labels (F and G share them).  The reference overwrites F's own column with g and
+    drops it, shrinking F as its loop runs (homogeneity.py:125-128; its value is kept in the fixture for the record).
+    The build evaluates every g inside the intact F u {g} (n_F + 1 curves) on both of its paths -- the batched one
+    (relax=True) and the call-by-call one (relax=False) -- pinned here against the oracle."""
+    from statdepth_amd.homogeneity import FunctionalHomogeneity
+    fx = load_golden("h_p3_overlap")
+    F, G = frame_df(fx["input"]["F"]), frame_df(fx["input"]["G"])
+    assert set(F.columns) & set(G.columns)
+    Fc = F.copy()
+    got = FunctionalHomogeneity([F], [G], method="p3", relax=relax, quiet=True).homogeneity()
+    Fx, Gx = F.to_numpy(), G.to_numpy()
+    nF = Fx.shape[1]
+    in_F = [oracle.univariate_depths(np.concatenate([Fx, Gx[:, c:c + 1]], axis=1), [nF], 2, relax)[0]
+            for c in range(Gx.shape[1])]
+    g_depths = oracle.univariate_depths(Gx, None, 2, relax)
+    want = max(in_F) / g_depths.max() if g_depths.max() > 0 else np.nan
+    if np.isnan(want):
+        assert not np.isfinite(float(got))
+    else:
+        assert abs(float(got) - want) <= TOL
+    assert F.equals(Fc)
+    if relax:
+        assert abs(float(got) - fx["reference_value"][0]) > 1e-6      # the quirk is NOT reproduced
+
+
+@pytest.mark.parametrize("containment", ["simplex", "l1"])
+@pytest.mark.parametrize("method", ["p1", "p2", "p3", "p4"])
+def test_pointcloud_homogeneity_vs_restatement(oracle, method, containment):
+    """PointcloudHomogeneity (homogeneity.py:155-200; the reference cannot run it on pandas >= 2): batched external-point
+    launches against the definition restated with the oracle -- depth of g inside F u {g}, n_F + 1 points."""
+    from statdepth_amd.homogeneity import PointcloudHomogeneity
+    rng = np.random.default_rng(31)
+    F = pd.DataFrame(rng.normal(size=(13, 2)))
+    G = pd.DataFrame(rng.normal(size=(13, 2)) * 0.8 + 0.2)     # same labels as F: rows 0..12
+
+    def depths(P):
+        return oracle.pointcloud_depths(P) if containment == "simplex" else oracle.l1_depth(P)
+
+    def inside(host, pt):
+        Hp = np.concatenate([host, pt[None, :]])
+        return (oracle.pointcloud_depths(Hp, [len(host)]) if containment == "simplex"
+                else oracle.l1_depth(Hp, [len(host)]))[0]
+
+    Fx, Gx = F.to_numpy(), G.to_numpy()
+    dF, dG = depths(Fx), depths(Gx)
+    assert (dF == dF.max()).sum() == 1 and (dG == dG.max()).sum() == 1      # a unique deepest point in each sample
+    g_in_F = inside(Fx, Gx[np.argmax(dG)])
+    p3 = max(inside(Fx, g) for g in Gx) / dG.max()
+    want = {"p1": g_in_F / dF.max(), "p2": 1 - abs(g_in_F - dF.max()), "p3": p3,
+            "p4": abs(p3 - inside(Fx, Fx[np.argmax(dF)]) / dF.max()) * abs(p3 - inside(Gx, Gx[np.argmax(dG)]) / dG.max())}[method]
+    h = PointcloudHomogeneity(F, G, method=method, containment=containment)
+    assert abs(float(h.homogeneity()) - want) <= 1e-12 * max(1.0, abs(want))
+    assert_depths_close(h.F_depths().to_numpy(), dF, TOL)
+    assert_depths_close(h.G_depths().to_numpy(), dG, TOL)
+
+
+def test_duplicate_column_labels_are_refused():
+    """Decision pinned against _helper.py:32: with duplicated labels the reference merges curves inside its bands and
+    raises TypeError for every target whose label is duplicated, i.e. for the default call (fixture g11_duplabels holds
+    what it does).  The build refuses such frames with a ValueError before touching the device."""
+    from statdepth_amd import FunctionalDepth
+    fx = load_golden("g11_duplabels")
+    df = frame_df(fx["input"])
+    assert not df.columns.is_unique
+    ref_default = [c for c in fx["calls"] if c["to_compute"] is None]
+    assert all(c.get("raises") == "TypeError" for c in ref_default)
+    for relax in (True, False):
+        for tc in (None, ["a"], ["b"]):
+            with pytest.raises(ValueError, match="unique"):
+                FunctionalDepth([df], to_compute=tc, relax=relax)
+    with pytest.raises(ValueError, match="unique"):
+        FunctionalDepth([df], K=2, relax=True)
