@@ -1,17 +1,23 @@
 #!/usr/bin/env python3
 """bench.py -- curve-pairs/s of modified band depth (J=2) on MI355X.
 
-Workload (BASELINE.json configs[1] at N=1): every rank owns n_loc = 10 000 synthetic
-random-walk curves x T = 1 000 timepoints (fp64, time-major); the data set is the
-union of all ranks' curves (n = N * n_loc), each rank computes the exact MBD
-containment totals of its own curves against the full set.  One step = one pass of
-the hot path: (N > 1: RCCL all-gather of the curve blocks) + sd_mbd_counts on the
-resident matrix.  value = ordered (target, other) curve pairs evaluated over all T
-timepoints per second, whole job.
+Headline workload (BASELINE.json configs[1] at N=1): every rank owns n_loc = 10 000 synthetic random-walk curves x
+T = 1 000 timepoints (fp64, time-major); the data set is the union of all ranks' curves (n = N * n_loc), each rank
+computes the exact MBD containment totals of its own curves against the full set.  One step = one pass of the hot
+path: (N > 1: the RCCL exchange of the curve blocks) + the rank kernels on the resident matrix.  value = ordered
+(target, other) curve pairs evaluated over all T timepoints per second, whole job.
+
+N = 1: the timed steps ROTATE over --rotate distinct matrices (default 4 x 80 MB > the 256 MiB Infinity Cache), so every
+step streams its matrix from HBM; the same loop replayed on ONE matrix (cache-resident, what round 1 reported) is
+printed beside it as `replay`.  `extras` holds the secondary workloads (config 3 on one GPU, the 10^5 x 10^3 stretch
+case, the tie-heavy variant, strict depth, L1, sampled simplex), each checked against the oracle on a sample in this
+run.  N > 1: `extras` holds config 3 (10^5 curves x 256 timepoints in all, strong scaling, both decompositions) and
+config 5 (10^6 points in R^3 through sharded_pointcloud).
 
 Prints ONE JSON line (rank 0).
 """
 import argparse
+import glob
 import json
 import os
 import sys
@@ -25,22 +31,158 @@ sys.path.insert(0, ROOT)
 HBM_PEAK = 8.0e12          # B/s, MI355X spec (MI355X_MICROARCH.md)
 
 
-def pmc_traffic(kernel, n, T, J):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc summary (profiles/), collected in
-    separate FETCH_SIZE / WRITE_SIZE passes and corrected as MI355X_MICROARCH.md prescribes (FETCH_SIZE x2 on
-    gfx950, calibrated on a kernel of known traffic).  Only valid for the workload it was measured on."""
+def pmc_traffic(kernels, n, T, J):
+    """HBM bytes per step from the committed rocprofv3 --pmc summary (profiles/), collected in separate FETCH_SIZE /
+    WRITE_SIZE passes and corrected as MI355X_MICROARCH.md prescribes (FETCH_SIZE x2 on gfx950, calibrated on a kernel of
+    known traffic).  Only valid for the workload it was measured on; returns (bytes, source file) or (None, None)."""
     if (n, T, J) != (10000, 1000, 2):
-        return None
-    import glob
+        return None, None
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic*.json")))
-    if not files:
-        return None
-    with open(files[-1]) as f:
-        ks = json.load(f)["kernels"]
-    for name, d in ks.items():
-        if kernel in name and "hbm_bytes_per_launch_corrected" in d:
-            return d["hbm_bytes_per_launch_corrected"]
-    return None
+    for path in reversed(files):
+        with open(path) as f:
+            doc = json.load(f)
+        ks = doc.get("kernels", {})
+        got = [d["hbm_bytes_per_launch_corrected"] for name, d in ks.items()
+               if any(k in name for k in kernels) and "hbm_bytes_per_launch_corrected" in d]
+        if got and doc.get("workload", "10000x1000") == "10000x1000" and len(got) >= len(kernels):
+            return float(sum(got)), os.path.relpath(path, ROOT)
+    return None, None
+
+
+def timed(fn, steps, warmup, stream, torch, barrier=None):
+    """(wall seconds, device ms per step) of `steps` calls of fn(i) behind `warmup` untimed ones."""
+    for i in range(warmup):
+        fn(i)
+    (barrier or torch.cuda.synchronize)()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record(stream)
+    for i in range(steps):
+        fn(i)
+    ev1.record(stream)
+    (barrier or torch.cuda.synchronize)()
+    dt = time.perf_counter() - t0
+    return dt, ev0.elapsed_time(ev1) / steps
+
+
+def walks(torch, T, n, seed, dev):
+    g = torch.Generator(device=dev).manual_seed(seed)
+    return torch.randn(T, n, dtype=torch.float64, device=dev, generator=g).cumsum(0)
+
+
+def extras_single_gpu(torch, dev, stream, lib, check, ALGOS, oracle, reps=10):
+    """Secondary workloads on one GPU, each verified against the oracle on a sample of targets."""
+    from statdepth_amd import engine
+    out = {}
+
+    def mbd_ms(X, J=2, algo="auto", reps=reps):
+        T, n = X.shape
+        res = torch.empty((n, J - 1), dtype=torch.int64, device=dev)
+        a = ALGOS[algo]
+        wsb = lib.sd_mbd_workspace_bytes(T, n, n, 1, n, J, a)
+        ws = torch.empty(max(int(wsb), 8), dtype=torch.uint8, device=dev)
+
+        def step(_):
+            check(lib.sd_mbd_counts(X.data_ptr(), T, n, n, 1, 0, n, J, a, res.data_ptr(), ws.data_ptr(), wsb,
+                                    stream.cuda_stream))
+        _, ms = timed(step, reps, 2, stream, torch)
+        return ms, res
+
+    def rate(T, n, ms):
+        return float(n) * (n - 1) / (ms * 1e-3)
+
+    # config 3 on one GPU, the stretch case, the tie-heavy variant of config 2
+    for key, (T, n, seed, nt) in {"config3_one_gpu": (256, 100000, 1235, 5), "stretch_1e5x1e3": (1000, 100000, 1238, 3)}.items():
+        X = walks(torch, T, n, seed, dev)
+        ms, res = mbd_ms(X, reps=5)
+        tg = np.linspace(0, n - 1, nt).astype(np.int64)
+        want = oracle.mbd_counts(X.cpu().numpy(), tg, 2)
+        assert (res[torch.from_numpy(tg).to(dev)].cpu().numpy() == want).all(), key
+        out[key] = {"workload": f"MBD J=2, {n} curves x {T} timepoints, 1 GPU", "ms": ms, "curve_pairs_per_s": rate(T, n, ms),
+                    "roofline_frac": (8.0 * T * 2 * n + 8.0 * n) / (ms * 1e-3) / HBM_PEAK, "checked_targets": int(nt)}
+        del X, res
+    Xh = np.round(np.random.default_rng(1234).normal(size=(1000, 10000)).cumsum(axis=0), 1)
+    dup = np.random.default_rng(7).choice(10000, size=100, replace=False)
+    Xh[:, dup] = Xh[:, (dup + 1) % 10000]
+    ms, res = mbd_ms(torch.from_numpy(Xh).to(dev))
+    assert (res.cpu().numpy() == oracle.mbd_counts_ranksort(Xh, 2)).all(), "ties variant"
+    out["config2_ties"] = {"workload": "config 2 rounded to 0.1 + 1 % duplicated curves", "ms": ms,
+                           "curve_pairs_per_s": rate(1000, 10000, ms), "checked_targets": 10000}
+    # strict band depth (relax=False), 2 000 banded curves x 1 000 timepoints
+    rng = np.random.default_rng(11)
+    Xs = np.sort(rng.normal(size=2000))[None, :] * 3.0 + rng.normal(size=(1000, 2000)) * 0.3
+    Xd = torch.from_numpy(Xs).to(dev)
+    T, n = Xs.shape
+    res = torch.empty((n, 1), dtype=torch.int64, device=dev)
+    wsb = lib.sd_bd_strict_workspace_bytes(T, n, n, 1, n)
+    ws = torch.empty(int(wsb), dtype=torch.uint8, device=dev)
+    _, ms = timed(lambda _: check(lib.sd_bd_strict_counts(Xd.data_ptr(), T, n, n, 1, 0, n, res.data_ptr(), ws.data_ptr(), wsb,
+                                                         stream.cuda_stream)), 3, 1, stream, torch)
+    tg = np.arange(0, n, 250)
+    assert (res.cpu().numpy()[tg, 0] == oracle.bd_strict_counts(Xs, tg)).all(), "strict"
+    out["strict_2000x1000"] = {"workload": "strict band depth J=2, 2000 banded curves x 1000 timepoints", "ms": ms,
+                               "pair_tests_per_s": n * (n - 1) * (n - 2) / 2 / (ms * 1e-3), "checked_targets": len(tg)}
+    # L1 depth and sampled simplicial depth
+    P = np.random.default_rng(1237).normal(size=(100000, 3))
+    Pd = torch.from_numpy(P).to(dev)
+    o = torch.empty(100000, dtype=torch.float64, device=dev)
+    _, ms = timed(lambda _: check(lib.sd_l1_depth(Pd.data_ptr(), 100000, 3, 0, 100000, o.data_ptr(), stream.cuda_stream)),
+                  3, 1, stream, torch)
+    tg = np.arange(0, 100000, 3125)
+    assert np.max(np.abs(o.cpu().numpy()[tg] - oracle.l1_depth(P, tg))) <= 1e-12, "l1"
+    out["l1_1e5x3"] = {"workload": "L1 depth, 10^5 points in R^3", "ms": ms, "point_pairs_per_s": 1e10 / (ms * 1e-3),
+                       "checked_targets": len(tg)}
+    oc = torch.empty(100000, dtype=torch.int64, device=dev)
+    _, ms = timed(lambda _: check(lib.sd_pointcloud_simplex_sampled(Pd.data_ptr(), 100000, 3, 0, 100000, 1e-7, 256, 1237,
+                                                                   oc.data_ptr(), stream.cuda_stream)), 3, 1, stream, torch)
+    tg = np.arange(0, 100000, 500)
+    assert (oc.cpu().numpy()[tg] == oracle.simplex_sampled(P, tg, samples=256, seed=1237)).all(), "simplex d=3"
+    out["simplex_sampled_d3"] = {"workload": "10^5 points in R^3, 256 tetrahedra per point", "ms": ms,
+                                 "simplex_tests_per_s": 1e5 * 256 / (ms * 1e-3), "checked_targets": len(tg)}
+    C = np.random.default_rng(1236).normal(size=(500, 50, 8)).cumsum(axis=1)
+    C[:8] *= 0.02
+    Cd = torch.from_numpy(C).to(dev)
+    oc = torch.empty(500, dtype=torch.int64, device=dev)
+    _, ms = timed(lambda _: check(lib.sd_multi_simplex_sampled(Cd.data_ptr(), 500, 50, 8, 0, 500, 1, 1e-7, 256, 1236,
+                                                              oc.data_ptr(), stream.cuda_stream)), 3, 1, stream, torch)
+    tg = np.arange(0, 500, 31)
+    assert (oc.cpu().numpy()[tg] == oracle.simplex_sampled(C, tg, relax=True, samples=256, seed=1236)).all(), "simplex d=8"
+    out["simplex_sampled_d8"] = {"workload": "500 curves x 50 timepoints x 8 features, 256 subsets per target (config 4 shape)",
+                                 "ms": ms, "simplex_tests_per_s": 500 * 256 * 50 / (ms * 1e-3), "checked_targets": len(tg)}
+    return out
+
+
+def extras_multi_gpu(torch, dist, dev, rank, N, reps=5):
+    """Configs 3 and 5 of BASELINE.json across the N ranks (strong scaling: the data set is fixed, the ranks share it)."""
+    from statdepth_amd.distributed import sharded_mbd_counts, sharded_pointcloud
+    stream = torch.cuda.current_stream(dev)
+    out = {}
+
+    def barrier():
+        dist.barrier()
+        torch.cuda.synchronize()
+
+    def tmax(dt):
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        return float(tt.item())
+
+    n, T = 100000, 256
+    sizes = [n // N + (1 if r < n % N else 0) for r in range(N)]
+    X_loc = walks(torch, T, sizes[rank], 1235 + rank, dev)
+    for mode in ("time", "targets"):
+        dt, _ = timed(lambda _: sharded_mbd_counts(X_loc, J=2, sizes=sizes, mode=mode), reps, 2, stream, torch, barrier)
+        dt = tmax(dt)
+        out[f"config3_{mode}"] = {"workload": f"MBD J=2, {n} curves x {T} timepoints over {N} GPUs ({mode}-sharded)",
+                                  "scaling": "strong", "ms": dt / reps * 1e3, "curve_pairs_per_s": float(n) * (n - 1) / (dt / reps)}
+    npts = 1000000
+    P_loc = torch.from_numpy(np.random.default_rng(1237 + rank).normal(size=(npts // N, 3))).to(dev)
+    for cont, kw, units in (("simplex", {"samples": 4096, "seed": 1237}, npts * 4096.0), ("l1", {}, float(npts) * npts)):
+        dt, _ = timed(lambda _: sharded_pointcloud(P_loc, cont, **kw), 2, 1, stream, torch, barrier)
+        dt = tmax(dt)
+        out[f"config5_{cont}"] = {"workload": f"10^6 points in R^3 over {N} GPUs, {cont}" + (" (4096 sampled tetrahedra per point)" if kw else ""),
+                                  "scaling": "strong", "ms": dt / 2 * 1e3, "units_per_s": units / (dt / 2)}
+    return out
 
 
 def main():
@@ -52,18 +194,23 @@ def main():
     ap.add_argument("--T", type=int, default=1000)
     ap.add_argument("--J", type=int, default=2)
     ap.add_argument("--algo", default="auto", choices=["auto", "pairwise", "rank"])
+    ap.add_argument("--rotate", type=int, default=4,
+                    help="distinct matrices the timed steps cycle through at N = 1 (4 x 80 MB > 256 MiB Infinity Cache); "
+                         "1 = replay one matrix")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--cpu-targets", type=int, default=10000)
     ap.add_argument("--variant", default="walk", choices=["walk", "ties"],
                     help="walk: continuous random walks (headline); ties: the same rounded to 1 decimal with 1 %% "
                          "duplicated curves (SURVEY.md 8(d) config 2 variant)")
+    ap.add_argument("--mode", default="auto", choices=["auto", "time", "targets"], help="multi-GPU decomposition")
     ap.add_argument("--force-dist", action="store_true",
                     help="run the torch.distributed path even at world size 1 (exercises RCCL on one GPU)")
     args = ap.parse_args()
 
     import torch
     import torch.distributed as dist
-    from statdepth_amd import _native, engine
+    from statdepth_amd import _native
     from statdepth_amd._native import ALGOS, check
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -84,16 +231,23 @@ def main():
 
     T, n_loc, J = args.T, args.n_loc, args.J
     n = n_loc * N
-    # synthetic curves: random walks (SURVEY.md 8(d) config 2 recipe), one block per rank
-    rng = np.random.default_rng(1234 + rank)
-    X_host = rng.normal(size=(T, n_loc)).cumsum(axis=0)
-    if args.variant == "ties":
-        X_host = np.round(X_host, 1)
-        dup = rng.choice(n_loc, size=max(1, n_loc // 100), replace=False)
-        X_host[:, dup] = X_host[:, (dup + 1) % n_loc]
-    X_loc = torch.from_numpy(X_host).to(dev)                       # [T, n_loc] time-major, resident in HBM
-    X_all = X_loc
-    out = torch.empty((n_loc, J - 1), dtype=torch.int64, device=dev)
+    K = 1 if use_dist else max(1, args.rotate)
+
+    def make_host(seed):
+        # synthetic curves: random walks (SURVEY.md 8(d) config 2 recipe), one block per rank
+        rng = np.random.default_rng(seed)
+        X = rng.normal(size=(T, n_loc)).cumsum(axis=0)
+        if args.variant == "ties":
+            X = np.round(X, 1)
+            dup = rng.choice(n_loc, size=max(1, n_loc // 100), replace=False)
+            X[:, dup] = X[:, (dup + 1) % n_loc]
+        return X
+
+    X_host = make_host(1234 + rank)
+    mats = [torch.from_numpy(X_host).to(dev)]                     # [T, n_loc] time-major, resident in HBM
+    for i in range(1, K):
+        mats.append(torch.from_numpy(make_host(4321 + i)).to(dev))
+    outs = [torch.empty((n_loc, J - 1), dtype=torch.int64, device=dev) for _ in range(K)]
     algo = ALGOS[args.algo]
     wsb = 0 if use_dist else lib.sd_mbd_workspace_bytes(T, n, n, 1, n_loc, J, algo)
     ws = torch.empty(max(int(wsb), 8), dtype=torch.uint8, device=dev)
@@ -102,33 +256,21 @@ def main():
     from statdepth_amd.distributed import sharded_mbd_counts
     sizes = [n_loc] * N
 
-    def step():
+    def step_on(k):
         if use_dist:
-            # product multi-GPU path (statdepth_amd/distributed.py): time-sharded for the rank kernels
-            # (RCCL all-to-all of curve blocks -> per-curve partial totals -> reduce-scatter), target-sharded
-            # (all-gather) for --algo pairwise
-            out.copy_(sharded_mbd_counts(X_loc, J=J, algo=args.algo, sizes=sizes))
+            # product multi-GPU path (statdepth_amd/distributed.py): time-sharded for the rank kernels (RCCL all-to-all of
+            # curve blocks -> per-curve partial totals -> reduce-scatter), target-sharded (all-gather) for --algo pairwise
+            outs[0].copy_(sharded_mbd_counts(mats[0], J=J, algo=args.algo, sizes=sizes, mode=args.mode))
         else:
-            check(lib.sd_mbd_counts_range(X_all.data_ptr(), T, n, n, 1, rank * n_loc, n_loc, J, algo,
-                                          out.data_ptr(), ws.data_ptr(), wsb, stream.cuda_stream))
+            check(lib.sd_mbd_counts_range(mats[k].data_ptr(), T, n, n, 1, rank * n_loc, n_loc, J, algo,
+                                          outs[k].data_ptr(), ws.data_ptr(), wsb, stream.cuda_stream))
 
     def barrier():
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record(stream)
-    for _ in range(args.steps):
-        step()
-    ev1.record(stream)
-    barrier()
-    dt = time.perf_counter() - t0
-    dev_ms = ev0.elapsed_time(ev1) / args.steps          # device time per step on the launch stream
+    dt, dev_ms = timed(lambda i: step_on(i % K), args.steps, args.warmup, stream, torch, barrier)
     if use_dist:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -136,32 +278,56 @@ def main():
     ms_per_step = dt / args.steps * 1e3
     pairs_per_step = float(n_loc) * N * (n - 1)          # ordered (target, other) pairs, whole job
     value = pairs_per_step / (dt / args.steps)
+    replay = None
+    if K > 1:                                            # the same loop on ONE matrix: the working set stays in the Infinity Cache
+        rdt, rdev = timed(lambda i: step_on(0), args.steps, args.warmup, stream, torch, barrier)
+        replay = {"ms_per_step": rdt / args.steps * 1e3, "kernel_ms": rdev,
+                  "note": "one 80 MB matrix replayed back to back (Infinity-Cache resident)"}
 
-    result_sum = int(out.sum().item())
+    result_sum = int(outs[0].sum().item())
+    extras = None
+    if not args.no_extras and args.variant == "walk" and (n_loc, T, J) == (10000, 1000, 2):
+        if N > 1:
+            extras = extras_multi_gpu(torch, dist, dev, rank, N)
     if rank == 0:
         used = "rank" if (args.algo == "rank" or (args.algo == "auto" and J <= 3)) else "pairwise"
-        # dominant kernel of the step: the bucket rank kernel (n <= 16384, J <= 3), the value-bucket sort of the large-n
-        # route, or the pairwise kernel
-        kern = "mbd_pairwise_kernel" if used == "pairwise" else ("rank_bucket_kernel" if n <= 16384 else "bucket_rank_kernel")
+        if used == "pairwise":
+            kerns = ["mbd_pairwise_kernel"]
+        elif n <= 10240 and n > 1024 and J == 2:
+            kerns = ["rank_bitmap_kernel", "rank_bucket_kernel", "rank_finalize"]
+        elif n <= 16384:
+            kerns = ["rank_bucket_kernel", "rank_finalize"]
+        else:
+            kerns = ["bucket_rank_kernel"]
         bytes_alg = 8.0 * T * (n + n_loc) + 8.0 * n_loc * (J - 1)   # per GPU per call
         achieved = bytes_alg / (dev_ms * 1e-3)
+        traffic, source = pmc_traffic(kerns, n, T, J) if N == 1 else (None, None)
+        mode = args.mode if args.mode != "auto" else ("time" if used == "rank" else "targets")
         line = {
             "metric": "curve-pairs/sec (MBD)", "value": value, "unit": "curve-pairs/s",
             "n_gpus": N, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"MBD J={J}: {n} curves x {T} timepoints (n_loc={n_loc} targets per GPU), fp64 "
-                                   f"random walks{' rounded to 0.1 + 1% duplicates' if args.variant == 'ties' else ''}, time-major", "algorithm": used,
+                                   f"random walks{' rounded to 0.1 + 1% duplicates' if args.variant == 'ties' else ''}, time-major"
+                                   + (f"; {K} distinct matrices in rotation ({K * T * n_loc * 8 / 2**20:.0f} MiB > Infinity Cache)" if K > 1 else ""),
+                       "algorithm": used,
                        "parallelism": (f"single GPU" if N == 1 else
-                                       (f"targets sharded x{N}, RCCL all-gather of curve blocks" if used == "pairwise" else
-                                        f"curves owned x{N}, timepoints sharded for the sort: RCCL all-to-all + reduce-scatter"))},
+                                       (f"targets sharded x{N}, RCCL all-gather of curve blocks" if mode == "targets" else
+                                        f"curves owned x{N}, timepoints sharded for the ranking: RCCL all-to-all + reduce-scatter"))},
             "pair_timepoints_per_s": value * T,
             "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK, "traffic": pmc_traffic(kern, n, T, J) if N == 1 else None,
-                         "kernel": kern,
-                         "kernel_ms": dev_ms, "algorithmic_bytes": bytes_alg},
+                         "frac": achieved / HBM_PEAK, "traffic": traffic, "traffic_source": source,
+                         "hbm_rate": (traffic / (dev_ms * 1e-3) / 1e9) if traffic else None,
+                         "kernel": kerns[0], "kernels_of_step": kerns,
+                         "kernel_ms": dev_ms, "algorithmic_bytes": bytes_alg,
+                         "note": "kernel_ms = device time of one whole step (all kernels of the step) by HIP events on the launch "
+                                 "stream; achieved = algorithmic_bytes / kernel_ms, a lower bound for the dominant kernel"},
             "checksum": result_sum,
         }
+        if replay:
+            replay["roofline_frac"] = bytes_alg / (replay["kernel_ms"] * 1e-3) / HBM_PEAK
+            line["replay"] = replay
         if not args.no_cpu_baseline and N == 1:
             import oracle
             oracle.build()
@@ -172,14 +338,28 @@ def main():
             t1 = time.perf_counter()
             want = oracle.mbd_counts(X_host, tg, J)
             cpu_dt = time.perf_counter() - t1
-            got = out[:m_cpu].cpu().numpy()
+            got = outs[0][:m_cpu].cpu().numpy()
             assert (got == want).all(), "HIP counts differ from the CPU oracle on the baseline sample"
             line["cpu_baseline"] = {
                 "value": m_cpu * (n - 1) / cpu_dt, "unit": "curve-pairs/s", "cores": oracle.num_threads(),
                 "kind": "port",
-                "sample": f"oracle_mbd_counts (C, OpenMP) on the first {m_cpu} of {n_loc} targets x all {n} curves x "
-                          f"{T} timepoints, {cpu_dt:.2f} s; work is linear in #targets",
+                "sample": f"oracle_mbd_counts (C, OpenMP; the reference's O(n^2 T) enumeration in closed form) on the first {m_cpu} "
+                          f"of {n_loc} targets x all {n} curves x {T} timepoints, {cpu_dt:.2f} s; work is linear in #targets",
             }
+            t1 = time.perf_counter()
+            want2 = oracle.mbd_counts_ranksort(X_host, J)
+            cpu_dt2 = time.perf_counter() - t1
+            assert (outs[0].cpu().numpy() == want2).all(), "HIP counts differ from the CPU rank-sort oracle"
+            line["cpu_baseline_rank"] = {
+                "value": n_loc * (n - 1) / cpu_dt2, "unit": "curve-pairs/s", "cores": oracle.num_threads(), "kind": "port",
+                "sample": f"oracle_mbd_counts_ranksort (C, OpenMP): the GPU's own O(n T log n) rank formulation, all {n_loc} "
+                          f"targets, {cpu_dt2:.2f} s -- the like-for-like CPU number",
+            }
+            if not args.no_extras and args.variant == "walk" and (n_loc, T, J) == (10000, 1000, 2):
+                del mats[1:], outs[1:]
+                extras = extras_single_gpu(torch, dev, stream, lib, check, ALGOS, oracle)
+        if extras:
+            line["extras"] = extras
         print(json.dumps(line), flush=True)
     if use_dist:
         dist.destroy_process_group()

@@ -56,6 +56,9 @@ enum sd_mbd_algo {
 
 /* ---- library / device ---------------------------------------------------- */
 int sd_abi_version(void);
+/* 0 for the product library.  1 for libstatdepth_hip_xcheck.so, the -DSD_CROSSCHECK build of the same sources that
+ * also holds the retired kernel generations and honours the SD_* environment switches selecting them (tests only). */
+int sd_is_crosscheck_build(void);
 const char *sd_last_error(void);
 int sd_device_count(void);
 /* name (e.g. "gfx950...") and CU count of device `dev`; name buffer >= 64 bytes */

@@ -41,6 +41,8 @@ def lib():
                                        c_lp, ctypes.c_long, ctypes.c_int, ctypes.c_int, c_ip]
         L.oracle_mbd_counts.argtypes = [c_dp, ctypes.c_long, ctypes.c_long, ctypes.c_long, ctypes.c_long,
                                         c_lp, ctypes.c_long, ctypes.c_int, c_ip]
+        L.oracle_mbd_counts_ranksort.argtypes = [c_dp, ctypes.c_long, ctypes.c_long, ctypes.c_long, ctypes.c_long,
+                                                 ctypes.c_int, ctypes.POINTER(ctypes.c_int64)]
         L.oracle_above_below.argtypes = [c_dp, ctypes.c_long, ctypes.c_long, ctypes.c_long, ctypes.c_long,
                                          c_lp, ctypes.c_long, c_ip]
         L.oracle_bd_strict_counts.argtypes = [c_dp, ctypes.c_long, ctypes.c_long, ctypes.c_long, ctypes.c_long,
@@ -120,6 +122,16 @@ def mbd_counts(X, targets=None, J=2):
     tg = _targets(targets, n)
     out = np.zeros((len(tg), J - 1), dtype=np.int64)
     rc = lib().oracle_mbd_counts(_dp(X), T, n, st, sn, _lp(tg), len(tg), J, _ip(out))
+    assert rc == 0
+    return out
+
+
+def mbd_counts_ranksort(X, J=2):
+    """The same totals for ALL curves by per-timepoint sorting (the rank formulation): int64[n, J-1]."""
+    X, st, sn = _x2d(X)
+    T, n = X.shape
+    out = np.zeros((n, J - 1), dtype=np.int64)
+    rc = lib().oracle_mbd_counts_ranksort(_dp(X), T, n, st, sn, J, _ip(out))
     assert rc == 0
     return out
 

@@ -180,6 +180,62 @@ int oracle_mbd_counts(const double *X, long T, long n, long st, long sn,
     return 0;
 }
 
+/* The same totals by the RANK formulation the GPU's default path uses: per timepoint one sort of
+ * the row, B = first position of the value, A = valid - position past its tie run; O(n T log n) instead of O(n^2 T).
+ * Same integers as oracle_mbd_counts (checked against it and the fixtures in tests/test_oracle_golden.py); bench.py
+ * times it as the like-for-like CPU baseline of the rank kernels.  Threads split the timepoints and add their
+ * per-curve totals at the end. */
+typedef struct { double v; long i; } oracle_kv;
+static int oracle_kv_cmp(const void *a, const void *b) {
+    double x = ((const oracle_kv *)a)->v, y = ((const oracle_kv *)b)->v;
+    return (x > y) - (x < y);
+}
+int oracle_mbd_counts_ranksort(const double *X, long T, long n, long st, long sn, int J, i64 *out) {
+    if (J < 2 || J > 16) return -1;
+    memset(out, 0, sizeof(i64) * (size_t)n * (size_t)(J - 1));
+    int fail = 0;
+#pragma omp parallel
+    {
+        oracle_kv *kv = (oracle_kv *)malloc(sizeof(oracle_kv) * (size_t)n);
+        u64 *acc = (u64 *)calloc((size_t)n * (size_t)(J - 1), sizeof(u64));
+        if (!kv || !acc) {
+#pragma omp atomic write
+            fail = 1;
+        } else {
+#pragma omp for schedule(dynamic, 4)
+            for (long t = 0; t < T; ++t) {
+                long nv = 0;
+                for (long i = 0; i < n; ++i) {
+                    double v = XAT(t, i);
+                    if (v == v) { kv[nv].v = v; kv[nv].i = i; ++nv; }
+                }
+                qsort(kv, (size_t)nv, sizeof(oracle_kv), oracle_kv_cmp);
+                u64 N = (u64)(n - nv);                       /* NaN curves: others of every valid target */
+                for (long p = 0; p < nv;) {
+                    long e = p + 1;
+                    while (e < nv && kv[e].v == kv[p].v) ++e;   /* tie run [p, e) */
+                    u64 B = (u64)p, A = (u64)(nv - e), v = (u64)(nv - 1);
+                    for (int j = 2; j <= J; ++j) {
+                        u64 s = 0;
+                        for (int k = 1; k <= j; ++k) {
+                            u64 w = binom_u64(N, j - k);
+                            if (!w) continue;
+                            s += w * (binom_u64(v, k) - binom_u64(A, k) - binom_u64(B, k));
+                        }
+                        for (long r = p; r < e; ++r) acc[kv[r].i * (J - 1) + (j - 2)] += s;
+                    }
+                    p = e;
+                }
+            }
+#pragma omp critical
+            for (long i = 0; i < n * (J - 1); ++i) out[i] += (i64)acc[i];
+        }
+        free(kv);
+        free(acc);
+    }
+    return fail ? -2 : 0;
+}
+
 /* Per-(target,timepoint) above/below counts (the integer quantity K1 produces):
  * AB[q][t][0]=A, [1]=B, over all n curves != target position (NaN counted in
  * neither).  Used by tests to check kernels at the finest granularity. */

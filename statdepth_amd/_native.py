@@ -9,6 +9,9 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libstatdepth_hip.so")
+# The cross-check build of the same sources (-DSD_CROSSCHECK: retired kernel generations + the environment switches that
+# select them).  TESTS ONLY: nothing in this package opens it; tests/conftest.py swaps it in for the comparisons.
+XCHECK_LIB_PATH = os.path.join(_HERE, "lib", "libstatdepth_hip_xcheck.so")
 
 SD_OK = 0
 SD_ERR_INVALID, SD_ERR_HIP, SD_ERR_NO_DEVICE, SD_ERR_UNSUPPORTED, SD_ERR_OVERFLOW, SD_ERR_WORKSPACE = 1, 2, 3, 4, 5, 6
@@ -20,6 +23,7 @@ _c = ctypes
 _vp, _i64, _int, _sz, _dbl, _u64 = _c.c_void_p, _c.c_int64, _c.c_int, _c.c_size_t, _c.c_double, _c.c_uint64
 SIGNATURES = {
     "sd_abi_version": (_int, []),
+    "sd_is_crosscheck_build": (_int, []),
     "sd_last_error": (_c.c_char_p, []),
     "sd_device_count": (_int, []),
     "sd_device_info": (_int, [_int, _c.c_char_p, _int, _c.POINTER(_int), _c.POINTER(_sz)]),
@@ -64,21 +68,29 @@ class StatdepthHipError(RuntimeError):
 _LIB = None
 
 
+def open_library(path):
+    """dlopen one build of the library and bind every symbol of include/statdepth_hip.h (no GPU needed)."""
+    if not os.path.exists(path):
+        raise RuntimeError(
+            f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C statdepth_amd/csrc`. statdepth_amd has no CPU fallback.")
+    lib = ctypes.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)       # AttributeError here = header/library mismatch
+        fn.restype = res
+        fn.argtypes = args
+    if lib.sd_abi_version() != 1:
+        raise RuntimeError(f"{os.path.basename(path)} ABI version mismatch")
+    return lib
+
+
 def load():
-    """Load the shared library (no GPU needed for this step)."""
+    """Load the product library (no GPU needed for this step)."""
     global _LIB
     if _LIB is None:
-        if not os.path.exists(LIB_PATH):
-            raise RuntimeError(
-                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
-                "or `make -C statdepth_amd/csrc`. statdepth_amd has no CPU fallback.")
-        lib = ctypes.CDLL(LIB_PATH)
-        for name, (res, args) in SIGNATURES.items():
-            fn = getattr(lib, name)       # AttributeError here = header/library mismatch
-            fn.restype = res
-            fn.argtypes = args
-        if lib.sd_abi_version() != 1:
-            raise RuntimeError("libstatdepth_hip.so ABI version mismatch")
+        lib = open_library(LIB_PATH)
+        if lib.sd_is_crosscheck_build() != 0:
+            raise RuntimeError("libstatdepth_hip.so was built with -DSD_CROSSCHECK: not the product library")
         _LIB = lib
     return _LIB
 

@@ -366,9 +366,9 @@ int launch_bd_strict(const double *Y, i64 T, i64 n, const i64 *targets, i64 m, i
         SD_HIP(hipMemsetAsync(xnan, 0, (size_t)nb * 4, s));
         dim3 g1((unsigned)((n + ST_THREADS - 1) / ST_THREADS), (unsigned)nb);
         dim3 g2((unsigned)((n + ST_THREADS - 1) / ST_THREADS), (unsigned)((n + ST_BCHUNK - 1) / ST_BCHUNK), (unsigned)nb);
-        const char *e1 = getenv("SD_STRICT_V1");             // 1: first-generation kernels (cross-check)
         const i64 W32 = (T + 31) / 32;
-        if (!(e1 && atoi(e1) == 1) && J == 2 && W32 <= ST_W32) {
+        // cross-check builds, SD_STRICT_V1 = 1: the first-generation kernels (they serve T > 1024 and J > 2 anyway)
+        if (xswitch("SD_STRICT_V1") != 1 && J == 2 && W32 <= ST_W32) {
             // second generation: 32-bit words, word-major image (fits the same workspace: 2 W32 n u32 <= 2 W n u64)
             dim3 g1b((unsigned)((n + ST_THREADS - 1) / ST_THREADS), (unsigned)W32, (unsigned)((nb + ST_TG - 1) / ST_TG));
             hipLaunchKernelGGL(strict_masks2_kernel, g1b, dim3(ST_THREADS), 0, s, Y, T, n, targets, q0, nb, (u32 *)masks, xnan);

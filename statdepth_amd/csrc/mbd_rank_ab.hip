@@ -1,12 +1,17 @@
-// mbd_rank_ab.hip -- K1+K2 rank formulation for n <= 16384 (the default path of sd_mbd_counts).
+// mbd_rank_ab.hip -- K1+K2 rank formulation for n <= 16384: the launcher of the rank path and the kernels that fold a
+// pair image.
 //
 // Same integers as the pairwise kernel and the reference's enumeration (_functional.py:246-251,
-// _containment.py:75-77): per (curve, timepoint) the counts B (others strictly below) and A (strictly
-// above) come from the curve's position in the sorted row, and C(v,j) - C(A,j) - C(B,j) is summed over t.
-// Three kernels, split so that none of them carries state it does not need (the 1024-thread sort
-// kernels live under a 128-VGPR cap; accumulators or a rarely taken branch compiled into them cost more
-// in scratch traffic than the work they save):
+// _containment.py:75-77): per (curve, timepoint) the counts B (others strictly below) and A (strictly above), and
+// C(v,j) - C(A,j) - C(B,j) summed over t.
 //
+// In the product library the rows are ranked by rank_bucket_kernel (mbd_rank_bucket.hip): J <= 3 folds in registers,
+// J >= 4 writes the pairs (B, A) of every (row, curve) as a uint16 pair image and
+//  C  rank_accumulate_kernel / rank_accumulate4_kernel -- fold the pairs and the per-row NaN counts into the int64
+//     totals of the requested targets.
+//
+// -DSD_CROSSCHECK builds (libstatdepth_hip_xcheck.so, loaded by the tests only) also carry the sort-based predecessors
+// the bucket kernel replaced, as independent implementations to compare against (SD_RANK_IMPL = 3, 2, 1):
 //  A  rank_packed_kernel  -- one workgroup sorts one row in LDS (rank_sort.h).  The curve index rides in
 //     the low log2(N) mantissa bits of the fp64 key, so v_min_f64 / v_max_f64 sort value and owner
 //     together and the holder of sorted position p knows which curve sits there: rank = p, handed to the
@@ -17,10 +22,6 @@
 //     sentinel class or (non-zero) into the zero class are left to kernel B as well.
 //  B  rank_search_kernel  -- the flagged rows: sort of the plain values, then every curve binary-searches
 //     its own value (lower bound = B, upper bound gives A; ties are exact by construction).
-//  C  rank_accumulate_kernel -- folds the (B, A) pairs and the per-row NaN counts into the int64 totals
-//     of the requested targets.
-//
-// HBM traffic per call: the matrix once (8 nT), the pair image written and read once (4 nT each).
 #include <stdlib.h>
 
 #include "sd_common.h"
@@ -29,6 +30,8 @@
 namespace sd {
 
 constexpr u32 AB_SPECIAL = 0xFFFFFFFFu;      // the curve is NaN at this timepoint: contributes nothing
+
+#ifdef SD_CROSSCHECK
 constexpr u32 ROW_DEFERRED = 0xFFFFFFFFu;    // nnan_out[r]: the packed kernel left row r to the search kernel
 
 template <int NT, int E>
@@ -255,6 +258,8 @@ __global__ __launch_bounds__(NT) void rank_search_kernel(const double *__restric
         if (t == 0) nnan_out[r] = nnan;
     }
 }
+#endif  // SD_CROSSCHECK (retired sort kernels)
+
 
 // ---------------------------------------------------------------------------------------------------
 // C: out[q][j] += sum over the batch's rows of the band counts of target q.
@@ -369,6 +374,7 @@ __global__ __launch_bounds__(1024) void rank_accumulate4_kernel(const u32 *__res
 // ---------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------
+#ifdef SD_CROSSCHECK
 static int ab_grid(i64 rows, int per_cu = 1) {
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) {
@@ -378,20 +384,21 @@ static int ab_grid(i64 rows, int per_cu = 1) {
     cus *= per_cu;
     return (int)(rows < cus ? rows : cus);
 }
+#endif
 
 static i64 ab_rows_per_batch(i64 T, i64 n) {
     i64 r = ((i64)1 << 30) / (n * 4);       // pair image <= 1 GiB
     if (r > 65536) r = 65536;               // and the bucket kernel's per-workgroup bitmap of set-aside rows (2048 bits)
-    if (const char *e = getenv("SD_RANK_ROWS_PER_BATCH")) {   // tests: force several batches on small inputs
-        i64 v = atoll(e);
-        if (v > 0 && v < r) r = v;
-    }
+    const i64 v = xswitch("SD_RANK_ROWS_PER_BATCH");   // cross-check builds: force several batches on small inputs
+    if (v > 0 && v < r) r = v;
     if (r < 1) r = 1;
     return r < T ? r : T;
 }
 
 // mbd_rank_bucket.hip
 bool mbd_rank_bucket_supported(i64 T, i64 n, int J);
+int mbd_rank_bucket_max_grid();
+size_t mbd_rank_bucket_partial_bytes(i64 n, int J);
 size_t mbd_rank_bucket_workspace_bytes(i64 rows, i64 n, int J);
 int launch_rank_bucket(const double *Y, i64 n, i64 row0, i64 rows, int J, u64 *partial, int *p32_out, int *G_out,
                        hipStream_t s);
@@ -405,15 +412,26 @@ bool mbd_rank_supported(i64 T, i64 n, int J) {
     return n >= 2 && n <= 16384 && J >= 2 && J <= JMAX;
 }
 
+// Which implementation ranks the rows: 4 = bucket kernel (J <= 3), 5 = bucket kernel in pair-image mode +
+// fold (J >= 4).  In -DSD_CROSSCHECK builds SD_RANK_IMPL selects the sort-based predecessors 3, 2, 1.
+static int rank_impl(i64 T, i64 n, int J) {
+    const int forced = (int)xswitch("SD_RANK_IMPL");
+    int impl = forced ? forced : 4;
+    if (impl == 4 && !mbd_rank_bucket_supported(T, n, J)) impl = (J >= 4) ? 5 : 3;
+    return impl;
+}
+
 size_t mbd_rank_workspace_bytes(i64 T, i64 n, int J) {
     if (!mbd_rank_supported(T, n, J)) return 0;
-    i64 rpb = ab_rows_per_batch(T, n);
+    const i64 rpb = ab_rows_per_batch(T, n);
+    const int impl = rank_impl(T, n, J);
+    if (impl == 4) return mbd_rank_bucket_workspace_bytes(rpb, n, J);      // no pair image on this path
     size_t need = align_up((size_t)rpb * n * 4, 256) + 2 * align_up((size_t)rpb * 4, 256) + 512;
-    if (mbd_rank_bucket_supported(T, n, J)) need += mbd_rank_bucket_workspace_bytes(rpb, n, J);
     size_t v1 = (size_t)(T < 1024 ? T : 1024) * (J <= 3 ? J - 1 : 0) * n * 8;   // first-generation kernel's partial sums
     return need > v1 ? need : v1;
 }
 
+#ifdef SD_CROSSCHECK
 template <int NT, int E>
 static int launch_sorts(const double *Y, i64 n, i64 row0, i64 rows, u32 *AB, u32 *nnan, int impl, hipStream_t s) {
     using C = R2Cfg<NT, E>;
@@ -435,8 +453,10 @@ static int launch_sorts(const double *Y, i64 n, i64 row0, i64 rows, u32 *AB, u32
     }
     auto kp = rank_packed_kernel<NT, E>;
     {
+#ifdef SD_TUNING
         const char *dbg = getenv("SD_RANKP_DBG");   // timing experiments only: 3 = no sort, ties ignored
         if (dbg && atoi(dbg) == 3) kp = rank_packed_kernel<NT, E, 3>;
+#endif
     }
     const size_t lds = C::LDS_BYTES + (size_t)NT * 8;
     SD_HIP(hipFuncSetAttribute((const void *)kp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -448,52 +468,54 @@ static int launch_sorts(const double *Y, i64 n, i64 row0, i64 rows, u32 *AB, u32
 
 int launch_mbd_rank_v1(const double *Y, i64 T, i64 n, const i64 *targets, i64 tbegin, i64 m, int J,
                        u64 *out, void *ws, size_t ws_bytes, hipStream_t s);
+#endif
 
 int launch_mbd_rank(const double *Y, i64 T, i64 n, const i64 *targets, i64 tbegin, i64 m, int J,
                     u64 *out, void *ws, size_t ws_bytes, hipStream_t s) {
     if (!mbd_rank_supported(T, n, J)) return fail(SD_ERR_UNSUPPORTED, "rank kernels cover 2 <= n <= 16384");
-    // SD_RANK_IMPL (A/B timing, cross-checks): 4 = bucket kernel (default where it applies), 3 = packed-key sort,
-    // 2 = search kernel for every row, 1 = first-generation kernel
-    const char *env = getenv("SD_RANK_IMPL");
-    int impl = env ? atoi(env) : 4;
-    if (impl == 4 && !mbd_rank_bucket_supported(T, n, J)) impl = (J >= 4) ? 5 : 3;   // 5: bucket kernel -> pair image -> fold
+    const int impl = rank_impl(T, n, J);
+#ifdef SD_CROSSCHECK
     if (impl == 1 && J <= 3) return launch_mbd_rank_v1(Y, T, n, targets, tbegin, m, J, out, ws, ws_bytes, s);
+#else
+    if (impl != 4 && impl != 5) return fail(SD_ERR_UNSUPPORTED, "rank implementation %d exists in cross-check builds only", impl);
+#endif
     const i64 rpb = ab_rows_per_batch(T, n);
     Carver cv(ws, ws_bytes);
+    if (impl == 4) {
+        // the bucket kernel ranks every row itself: partial totals per workgroup, no pair image, no search launch
+        u64 *partial = (u64 *)cv.take(mbd_rank_bucket_partial_bytes(n, J));
+        if (!partial) return fail(SD_ERR_WORKSPACE, "rank workspace too small (bucket kernel)");
+        for (i64 row0 = 0; row0 < T; row0 += rpb) {
+            const i64 rows = T - row0 < rpb ? T - row0 : rpb;
+            int rc, G = 0, p32 = 0;
+            if ((rc = launch_rank_bucket(Y, n, row0, rows, J, partial, &p32, &G, s))) return rc;
+            if ((rc = launch_rank_finalize(partial, G, p32, nullptr, nullptr, nullptr, rows, n, targets, tbegin, m, J, out,
+                                           row0 == 0, s)))
+                return rc;
+        }
+        return SD_OK;
+    }
     u32 *AB = (u32 *)cv.take((size_t)rpb * n * 4);
     u32 *nnan = (u32 *)cv.take((size_t)rpb * 4);
     if (!AB || !nnan) return fail(SD_ERR_WORKSPACE, "rank workspace too small");
-    u64 *partial = nullptr;
-    unsigned char *rowflag = nullptr;
-    if (impl == 4) {
-        const size_t pb = mbd_rank_bucket_workspace_bytes(rpb, n, J) - align_up((size_t)rpb, 256) - 512;
-        partial = (u64 *)cv.take(pb);
-        rowflag = (unsigned char *)cv.take((size_t)rpb);
-        if (!partial || !rowflag) return fail(SD_ERR_WORKSPACE, "rank workspace too small (bucket kernel)");
-    }
     for (i64 row0 = 0; row0 < T; row0 += rpb) {
         const i64 rows = T - row0 < rpb ? T - row0 : rpb;
         int rc;
-        int G = 0, p32 = 0;
-        if (impl == 4 && (rc = launch_rank_bucket(Y, n, row0, rows, J, partial, &p32, &G, s))) return rc;
         // E = 16 keys per thread throughout; smaller rows take smaller workgroups so that several rows are in
         // flight per CU (n = 4000: 4 workgroups of 256 threads per CU, 0.053 ms against 0.091 ms for 1024 x 4)
-        if (impl == 4) rc = SD_OK;
-        else if (impl == 5) rc = launch_rank_bucket_image(Y, n, row0, rows, AB, nnan, s);
+        if (impl == 5) rc = launch_rank_bucket_image(Y, n, row0, rows, AB, nnan, s);
+#ifdef SD_CROSSCHECK
         else if (n <= 1024) rc = launch_sorts<64, 16>(Y, n, row0, rows, AB, nnan, impl, s);
         else if (n <= 2048) rc = launch_sorts<128, 16>(Y, n, row0, rows, AB, nnan, impl, s);
         else if (n <= 4096) rc = launch_sorts<256, 16>(Y, n, row0, rows, AB, nnan, impl, s);
         else if (n <= 8192) rc = launch_sorts<512, 16>(Y, n, row0, rows, AB, nnan, impl, s);
         else rc = launch_sorts<1024, 16>(Y, n, row0, rows, AB, nnan, impl, s);
+#else
+        else rc = fail(SD_ERR_UNSUPPORTED, "sort-based rank kernels exist in cross-check builds only");
+#endif
         if (rc) return rc;
         dim3 grid((unsigned)((m + 63) / 64));
         const int first = row0 == 0;
-        if (impl == 4) {   // the bucket kernel ranked every row itself: no pair image, no search launch
-            if ((rc = launch_rank_finalize(partial, G, p32, nullptr, nullptr, nullptr, rows, n, targets, tbegin, m, J, out,
-                                           first, s)))
-                return rc;
-            continue;
-        }
         if (!targets && (n % 4) == 0 && (tbegin % 4) == 0 && (m % 4) == 0 && J <= 3) {
             SD_DISPATCH_J(J, hipLaunchKernelGGL((rank_accumulate4_kernel<J_>), grid, dim3(1024), 0, s, (const u32 *)AB,
                                                 (const u32 *)nnan, rows, n, tbegin, m, out, first));

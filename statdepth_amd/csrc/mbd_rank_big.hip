@@ -197,6 +197,7 @@ __global__ __launch_bounds__(SNT) void bucket_splitters_kernel(const double *__r
 }
 
 // P: grid = (ceil(n / 16384), rows)
+#ifdef SD_CROSSCHECK
 __global__ __launch_bounds__(1024) void bucket_partition_kernel(const double *__restrict__ Y, i64 n, i64 row0, int NB,
                                                                 const double *__restrict__ spl,
                                                                 u32 *__restrict__ bcnt, u32 *__restrict__ nnanrow,
@@ -268,6 +269,7 @@ __global__ __launch_bounds__(1024) void bucket_partition_kernel(const double *__
     }
     if (over) ovf[rb] = 1u;
 }
+#endif  // SD_CROSSCHECK
 
 // P' (default): the same partition with the scatter staged through LDS.  One workgroup takes 8 192 consecutive curves
 // of one row, orders them by value bucket inside LDS (local slot = LDS-atomic offset + local exclusive prefix of the
@@ -389,6 +391,7 @@ __device__ __forceinline__ u64 bk_bits(double v) { return (u64)__double_as_longl
 __device__ __forceinline__ double bk_dbl(u64 b) { return __longlong_as_double((long long)b); }
 
 // A: grid = (NB, rows)
+#ifdef SD_CROSSCHECK
 __global__ __launch_bounds__(BK_NT) void bucket_packed_kernel(i64 n, int NB, const u32 *__restrict__ bcnt,
                                                               const u32 *__restrict__ nnanrow,
                                                               const u32 *__restrict__ ovf,
@@ -476,6 +479,7 @@ __global__ __launch_bounds__(BK_NT) void bucket_packed_kernel(i64 n, int NB, con
         ab[rb * n + bidx[slot0 + j]] = v;
     }
 }
+#endif  // SD_CROSSCHECK
 
 
 // A' (default): grid = 8 * NB * ceil(rows / 8) (see the mapping below).  Ranks inside one value bucket WITHOUT a sort, the method of mbd_rank_bucket.hip:
@@ -831,10 +835,8 @@ static BigPlan big_plan(i64 T, i64 n) {
     p.NB = bucket_count(n);
     const size_t per_row = (size_t)n * 8 + (size_t)p.sstride * 8 + (size_t)p.NB * BK_C * 12 + (size_t)p.NB * 16 + 64;
     i64 r = (i64)(((size_t)3 << 29) / per_row);           // ~1.5 GiB of scratch per batch
-    if (const char *e = getenv("SD_RANK_ROWS_PER_BATCH")) {   // tests: force several batches on small inputs
-        i64 v = atoll(e);
-        if (v > 0 && v < r) r = v;
-    }
+    const i64 vb = xswitch("SD_RANK_ROWS_PER_BATCH");          // cross-check builds: several batches on small inputs
+    if (vb > 0 && vb < r) r = vb;
     if (r < 1) r = 1;
     if (r > T) r = T;
     if (r > 65535) r = 65535;
@@ -885,8 +887,7 @@ int launch_mbd_rank_big(const double *Y, i64 T, i64 n, const i64 *targets, i64 t
     u32 *bcnt = (u32 *)(zb + p.z_bcnt), *nnanrow = (u32 *)(zb + p.z_nnan), *ovf = (u32 *)(zb + p.z_ovf);
     u32 *bflag = (u32 *)(zb + p.z_bflag), *nanf = (u32 *)(zb + p.z_nanf);
 
-    const char *env = getenv("SD_BIG_IMPL");                 // 1: chunked route for every row (A/B timing, cross-check)
-    const bool buckets = !(env && atoi(env) == 1);
+    const bool buckets = xswitch("SD_BIG_IMPL") != 1;       // cross-check builds, 1: chunked route for every row
     const int NB = p.NB;
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) {
@@ -904,10 +905,11 @@ int launch_mbd_rank_big(const double *Y, i64 T, i64 n, const i64 *targets, i64 t
     constexpr size_t lds_sp_small = R2Cfg<128, 16>::LDS_BYTES, lds_sp = R2Cfg<256, 16>::LDS_BYTES;
     constexpr size_t lds_sp_big = R2Cfg<1024, 16>::LDS_BYTES;
     SD_HIP(hipFuncSetAttribute((const void *)k_sp_small, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sp_small));
-    auto k_bp = bucket_packed_kernel;
     auto k_br = bucket_rank_kernel;
-    const char *envA = getenv("SD_BIG_SORT");                 // 1: packed-key sort per value bucket (predecessor, cross-check)
-    const bool rank_nosort = !(envA && atoi(envA) == 1);
+#ifdef SD_CROSSCHECK
+    auto k_bp = bucket_packed_kernel;
+    const bool rank_nosort = xswitch("SD_BIG_SORT") != 1;   // 1: packed-key sort per value bucket (predecessor)
+#endif
     auto k_bs = bucket_search_kernel;
     const size_t lds_bk = BkCfg::LDS_BYTES + (size_t)BK_NT * 8;
     SD_HIP(hipFuncSetAttribute((const void *)k_cs, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BigCfg::LDS_BYTES));
@@ -915,7 +917,9 @@ int launch_mbd_rank_big(const double *Y, i64 T, i64 n, const i64 *targets, i64 t
     SD_HIP(hipFuncSetAttribute((const void *)k_sp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sp));
     SD_HIP(hipFuncSetAttribute((const void *)k_sp_big, hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)lds_sp_big));
+#ifdef SD_CROSSCHECK
     SD_HIP(hipFuncSetAttribute((const void *)k_bp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bk));
+#endif
     SD_HIP(hipFuncSetAttribute((const void *)k_br, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BR_LDS));
     SD_HIP(hipFuncSetAttribute((const void *)bucket_partition2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)((size_t)BP2_C * 14)));
@@ -933,20 +937,23 @@ int launch_mbd_rank_big(const double *Y, i64 T, i64 n, const i64 *targets, i64 t
                 hipLaunchKernelGGL(k_sp, dim3((unsigned)rows), dim3(256), lds_sp, s, Y, n, row0, NB, spl);
             else
                 hipLaunchKernelGGL(k_sp_big, dim3((unsigned)rows), dim3(1024), lds_sp_big, s, Y, n, row0, NB, spl);
-            const char *ep = getenv("SD_BIG_PART1");             // 1: first-generation partition (direct scatter), cross-check
-            if (ep && atoi(ep) == 1)
+#ifdef SD_CROSSCHECK
+            if (xswitch("SD_BIG_PART1") == 1)                    // first-generation partition (direct scatter)
                 hipLaunchKernelGGL(bucket_partition_kernel, dim3((unsigned)((n + 16383) / 16384), (unsigned)rows), dim3(1024),
                                    0, s, Y, n, row0, NB, (const double *)spl, bcnt, nnanrow, ovf, bval, bidx, ab, 0);
             else
+#endif
                 hipLaunchKernelGGL(bucket_partition2_kernel, dim3((unsigned)((n + BP2_C - 1) / BP2_C), (unsigned)rows),
                                    dim3(BP2_NT), (size_t)BP2_C * 14, s, Y, n, row0, NB, (const double *)spl, bcnt, nnanrow,
                                    ovf, bval, bidx, ab);
-            if (rank_nosort)
-                hipLaunchKernelGGL(k_br, dim3((unsigned)(8 * NB * ((rows + 7) / 8))), dim3(BR_NT), BR_LDS, s, n, rows, NB,
-                                   (const u32 *)bcnt,
+#ifdef SD_CROSSCHECK
+            if (!rank_nosort)
+                hipLaunchKernelGGL(k_bp, dim3((unsigned)NB, (unsigned)rows), dim3(BK_NT), lds_bk, s, n, NB, (const u32 *)bcnt,
                                    (const u32 *)nnanrow, (const u32 *)ovf, (const double *)bval, (const u32 *)bidx, bflag, ab);
             else
-                hipLaunchKernelGGL(k_bp, dim3((unsigned)NB, (unsigned)rows), dim3(BK_NT), lds_bk, s, n, NB, (const u32 *)bcnt,
+#endif
+                hipLaunchKernelGGL(k_br, dim3((unsigned)(8 * NB * ((rows + 7) / 8))), dim3(BR_NT), BR_LDS, s, n, rows, NB,
+                                   (const u32 *)bcnt,
                                    (const u32 *)nnanrow, (const u32 *)ovf, (const double *)bval, (const u32 *)bidx, bflag, ab);
             hipLaunchKernelGGL(k_bs, dim3((unsigned)NB, (unsigned)rows), dim3(BK_NT), BkCfg::LDS_BYTES, s, n, NB,
                                (const u32 *)bcnt, (const u32 *)nnanrow, (const u32 *)bflag, (const double *)bval,

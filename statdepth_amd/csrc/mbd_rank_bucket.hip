@@ -913,15 +913,20 @@ static int rb_cus() {
 bool mbd_rank_bucket_supported(i64 T, i64 n, int J) {
     (void)T;
     i64 nmin = 1;                          // measured faster than the sort kernels from n = 600 to 16384
+#ifdef SD_TUNING
     if (const char *e = getenv("SD_RB_MIN_N")) nmin = atoll(e);   // tuning experiments
+#endif
     return n > nmin && n <= 16384 && J >= 2 && J <= 3;
 }
 
 // upper bound of the grid the launcher will use (the partial totals are sized by it)
 int mbd_rank_bucket_max_grid() { return 2 * rb_cus(); }
 
+// the workgroups' partial totals: all this path keeps in HBM
+size_t mbd_rank_bucket_partial_bytes(i64 n, int J) { return align_up((size_t)mbd_rank_bucket_max_grid() * (J - 1) * n * 8, 256); }
 size_t mbd_rank_bucket_workspace_bytes(i64 rows, i64 n, int J) {
-    return align_up((size_t)mbd_rank_bucket_max_grid() * (J - 1) * n * 8, 256) + align_up((size_t)rows, 256) + 512;
+    (void)rows;
+    return mbd_rank_bucket_partial_bytes(n, J) + 512;
 }
 
 #ifndef RB_CAP
@@ -935,8 +940,9 @@ static int launch_bucket_cfg(const double *Y, i64 n, i64 row0, i64 rows, u64 *pa
     if constexpr (J == 2) {
         if (p32 == 2) kf = rank_bucket_kernel<NT, E, LNB, J, RB_CAP, U2, 0, true>;
     }
+#ifdef SD_TUNING
     if constexpr (E == 10 && J == 2 && LNB == 15 && U2 == 3) {
-        if (const char *d = getenv("SD_RB_DBG")) {        // timing experiments: truncated kernels
+        if (const char *d = getenv("SD_RB_DBG")) {        // timing experiments: truncated kernels (results invalid)
             switch (atoi(d)) {
                 case 1: kf = rank_bucket_kernel<NT, E, LNB, J, RB_CAP, U2, 1>; break;
                 case 2: kf = rank_bucket_kernel<NT, E, LNB, J, RB_CAP, U2, 2>; break;
@@ -947,6 +953,7 @@ static int launch_bucket_cfg(const double *Y, i64 n, i64 row0, i64 rows, u64 *pa
             }
         }
     }
+#endif
     const size_t lds = C::lds_bytes((int)n);
     if (lds > 163840) return fail(SD_ERR_UNSUPPORTED, "bucket kernel: %zu bytes of LDS for n=%lld", lds, (long long)n);
     SD_HIP(hipFuncSetAttribute((const void *)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -963,6 +970,7 @@ static int launch_bucket_j(const double *Y, i64 n, i64 row0, i64 rows, u64 *part
     // J = 3 stays at 16384: the wider prefix arrays push it further into scratch); first member pass: 3 x 16 bytes
 #define RB_ARGS Y, n, row0, rows, partial, p32, G, s
     const int E = (int)((n + 1023) / 1024);
+#ifdef SD_TUNING
     if (E == 10 && J == 2) {                              // tuning experiments on the config-2 shape
         const char *eu = getenv("SD_RB_U2"), *el = getenv("SD_RB_LNB");
         const int u2 = eu ? atoi(eu) : 3, lnb = el ? atoi(el) : 15;
@@ -973,6 +981,7 @@ static int launch_bucket_j(const double *Y, i64 n, i64 row0, i64 rows, u64 *part
         if (lnb == 13 && u2 == 3) return launch_bucket_cfg<1024, 10, 13, 2, 3>(RB_ARGS);
         if (lnb == 13 && u2 == 4) return launch_bucket_cfg<1024, 10, 13, 2, 4>(RB_ARGS);
     }
+#endif
     switch (E) {
         case 1: return launch_bucket_cfg<1024, 1, 13, J, 3>(RB_ARGS);
         case 2: return launch_bucket_cfg<1024, 2, 13, J, 3>(RB_ARGS);
@@ -1010,7 +1019,8 @@ int launch_rank_bucket_image(const double *Y, i64 n, i64 row0, i64 rows, u32 *AB
     return fail(SD_ERR_UNSUPPORTED, "bucket kernel covers n <= 16384");
 }
 
-// rows [row0, row0 + rows): bucket kernel; returns the grid used (number of partial blocks) in *G_out
+// rows [row0, row0 + rows): partial totals of every curve per workgroup; returns the grid used (number of partial
+// blocks) in *G_out
 int launch_rank_bucket(const double *Y, i64 n, i64 row0, i64 rows, int J, u64 *partial, int *p32_out, int *G_out,
                        hipStream_t s) {
     // one workgroup per CU; two where the kernel is built for 64 VGPRs (few keys per thread)
@@ -1022,7 +1032,7 @@ int launch_rank_bucket(const double *Y, i64 n, i64 row0, i64 rows, int J, u64 *p
     const u64 per_wg = (u64)((rows + G - 1) / G) * ((u64)(n - 1) * (u64)(n - 2) / 2);
     int p32 = (J == 2 && per_wg < ((u64)1 << 32)) ? 1 : 0;
     // ... and 2 * total stays below 2^32 too (2 * C(v,2) + 2 N v < n^2 per row): the kernel accumulates in 32 bits
-    if (p32 && (u64)((rows + G - 1) / G) * (u64)n * (u64)n < ((u64)1 << 32) && !getenv("SD_RB_ACC64")) p32 = 2;
+    if (p32 && (u64)((rows + G - 1) / G) * (u64)n * (u64)n < ((u64)1 << 32) && xswitch("SD_RB_ACC64") == 0) p32 = 2;
     *p32_out = p32;
     if (J == 2) return launch_bucket_j<2>(Y, n, row0, rows, partial, p32, G, s);
     if (J == 3) return launch_bucket_j<3>(Y, n, row0, rows, partial, p32, G, s);
@@ -1033,7 +1043,7 @@ int launch_rank_finalize(const u64 *partial, int G, int p32, const u32 *AB, cons
                          i64 rows, i64 n, const i64 *targets, i64 tbegin, i64 m, int J, u64 *out, int first,
                          hipStream_t s) {
     dim3 grid((unsigned)((m + 31) / 32));
-    if (J == 2 && p32 && !targets && !rowflag && n % 4 == 0 && tbegin % 4 == 0 && m % 4 == 0 && !getenv("SD_RB_FINAL1"))
+    if (J == 2 && p32 && !targets && !rowflag && n % 4 == 0 && tbegin % 4 == 0 && m % 4 == 0 && xswitch("SD_RB_FINAL1") == 0)
         hipLaunchKernelGGL(rank_finalize4_kernel, grid, dim3(256), 0, s, reinterpret_cast<const u32 *>(partial), G, n, tbegin, m,
                            out, first);
     else if (J == 2)

@@ -41,6 +41,12 @@ struct Carver {
     bool ok() const { return off <= cap; }
 };
 
+// Value of an environment switch that selects an alternative implementation for cross-checks (SD_RANK_IMPL,
+// SD_BIG_IMPL, SD_SIMPLEX_GENERIC, ...).  The product library (libstatdepth_hip.so) is built without -DSD_CROSSCHECK:
+// there this returns 0 for every name and no environment variable is read; libstatdepth_hip_xcheck.so (tests only)
+// reads the variable on every call.  xcheck.hip.
+long long xswitch(const char *name);
+
 // ---- launchers implemented in the kernel translation units ----
 // strided (t,i) -> time-major Y[t*n+i]
 int launch_to_time_major(const double *X, i64 T, i64 n, i64 st, i64 sn, double *Y, hipStream_t s);

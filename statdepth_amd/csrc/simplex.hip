@@ -472,8 +472,7 @@ static int launch_simplex_common(const double *P, i64 n, i64 T, int d, const i64
         dim3 grid((unsigned)blocks, (unsigned)mm);
 #define SX_FAST(D_) case D_: hipLaunchKernelGGL((simplex_kernel_fast<D_>), grid, dim3(SX_THREADS), 0, s, P, n, T, targets, \
                                                  relax, tol, total, per_thread, samples, seed, q0, out, sel); break;
-        const char *eg = getenv("SD_SIMPLEX_GENERIC");       // 1: the generic (scratch-memory) kernel, cross-check
-        if (eg && atoi(eg) == 1) {
+        if (xswitch("SD_SIMPLEX_GENERIC") == 1) {            // cross-check builds: the generic (scratch-memory) kernel
             hipLaunchKernelGGL(simplex_kernel, grid, dim3(SX_THREADS), 0, s, P, n, T, d, targets, relax, tol, total,
                                per_thread, samples, seed, q0, out, sel);
         } else {

@@ -69,3 +69,31 @@ def oracle():
     import oracle as o
     o.build()
     return o
+
+
+@pytest.fixture
+def xcheck(monkeypatch):
+    """Cross-check implementations live in libstatdepth_hip_xcheck.so (the -DSD_CROSSCHECK build of the same sources: the
+    retired kernel generations + the environment switches that select them); the product library has neither.
+
+        with xcheck(SD_RANK_IMPL="3"):
+            other = engine.mbd_counts(...)      # runs on the cross-check library with the switch set
+
+    Outside the `with` the engine is back on the product library."""
+    import contextlib
+    from statdepth_amd import _native
+    state = {}
+
+    @contextlib.contextmanager
+    def use(**env):
+        if "lib" not in state:
+            state["lib"] = _native.open_library(_native.XCHECK_LIB_PATH)
+            assert state["lib"].sd_is_crosscheck_build() == 1
+        product = _native.load()
+        with monkeypatch.context() as m:
+            for k, v in env.items():
+                m.setenv(k, str(v))
+            m.setattr(_native, "_LIB", state["lib"])
+            yield state["lib"]
+        assert _native._LIB is product
+    return use

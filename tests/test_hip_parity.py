@@ -228,7 +228,7 @@ def test_mbd_counts_range_vs_oracle(eng, oracle):
             assert (eng.mbd_counts_range(X, lo, m, 2, algo=algo) == want).all()
 
 
-def test_mbd_high_J(eng, oracle, monkeypatch):
+def test_mbd_high_J(eng, oracle, xcheck):
     rng = np.random.default_rng(5)
     X = rng.integers(0, 9, size=(12, 40)).astype(float)
     X[2, 3] = np.nan
@@ -240,13 +240,12 @@ def test_mbd_high_J(eng, oracle, monkeypatch):
     tg = np.arange(0, 3000, 111)
     for J in (4, 5):
         got = eng.mbd_counts(Y, None, J, algo="rank")
-        monkeypatch.setenv("SD_RANK_IMPL", "3")
-        assert (got == eng.mbd_counts(Y, None, J, algo="rank")).all()
-        monkeypatch.delenv("SD_RANK_IMPL")
+        with xcheck(SD_RANK_IMPL="3"):
+            assert (got == eng.mbd_counts(Y, None, J, algo="rank")).all()
         assert (got[tg] == oracle.mbd_counts(Y, tg, J)).all()
 
 
-def test_rank_implementations_cross_check(eng, oracle, monkeypatch):
+def test_rank_implementations_cross_check(eng, oracle, xcheck):
     """The four rank implementations (bucket kernel, packed keys + deferred rows, search for every row, first generation)
     are independent pieces of code: they must agree with each other and with the oracle on ties, near-ties
     (values equal above the index field of the packed key) and specials."""
@@ -259,10 +258,10 @@ def test_rank_implementations_cross_check(eng, oracle, monkeypatch):
     cont[4, :7] = [np.inf, -np.inf, np.nan, 0.0, -0.0, 1.79e308, -1.79e308]
     for X in (base, near, big, tiny, cont):
         want = oracle.mbd_counts(X, None, 2)
+        assert (eng.mbd_counts(X, None, 2, algo="rank") == want).all(), "product library"
         for impl in ("4", "3", "2", "1"):
-            monkeypatch.setenv("SD_RANK_IMPL", impl)
-            assert (eng.mbd_counts(X, None, 2, algo="rank") == want).all(), impl
-    monkeypatch.delenv("SD_RANK_IMPL")
+            with xcheck(SD_RANK_IMPL=impl):
+                assert (eng.mbd_counts(X, None, 2, algo="rank") == want).all(), impl
 
 
 def _bucket_rows(rng, T, n):
@@ -286,21 +285,19 @@ def _bucket_rows(rng, T, n):
 
 
 @pytest.mark.parametrize("n", [2, 3, 64, 65, 1000, 1025, 3000, 8192, 8193, 10000, 12345, 16384])
-def test_bucket_kernel_rows(eng, oracle, monkeypatch, n):
-    """mbd_rank_bucket.hip (SD_RANK_IMPL=4, the default for n <= 16384) against the packed-sort path on every
+def test_bucket_kernel_rows(eng, oracle, xcheck, n):
+    """mbd_rank_bucket.hip (the default for n <= 16384) against the packed-sort path of the cross-check build on every
     curve and against the oracle on a sample of targets."""
     rng = np.random.default_rng(n)
     X = _bucket_rows(rng, 16, n)
     for J in (2, 3):
         if n - 1 < J:
             continue
-        monkeypatch.setenv("SD_RANK_IMPL", "4")
         got = eng.mbd_counts(X, None, J, algo="rank")
-        monkeypatch.setenv("SD_RANK_IMPL", "3")
-        assert (got == eng.mbd_counts(X, None, J, algo="rank")).all()
+        with xcheck(SD_RANK_IMPL="3"):
+            assert (got == eng.mbd_counts(X, None, J, algo="rank")).all()
         tg = np.unique(np.linspace(0, n - 1, 48).astype(np.int64))
         assert (got[tg] == oracle.mbd_counts(X, tg, J)).all()
-    monkeypatch.delenv("SD_RANK_IMPL", raising=False)
 
 
 def test_bucket_kernel_many_rows_per_workgroup(eng, oracle):
@@ -598,19 +595,20 @@ def test_sharded_paths_world_size_one(eng, oracle):
         dist.destroy_process_group()
 
 
-def test_row_batching(eng, oracle, monkeypatch):
-    """Rows are processed in batches when the pair image / sorted scratch would exceed 1 GiB; force small batches."""
+def test_row_batching(eng, oracle, xcheck):
+    """Rows are processed in batches when the pair image / sorted scratch would exceed 1 GiB; the cross-check build of
+    the same launchers lets a switch force small batches."""
     rng = np.random.default_rng(77)
-    monkeypatch.setenv("SD_RANK_ROWS_PER_BATCH", "7")
     X = np.round(rng.normal(size=(40, 700)).cumsum(axis=0), 1)
     X[11, 5] = np.nan
-    for J in (2, 3):
-        assert (eng.mbd_counts(X, None, J, algo="rank") == oracle.mbd_counts(X, None, J)).all()
-    tg = np.array([3, 699, 0, 350])
-    assert (eng.mbd_counts(X, tg, 2, algo="rank") == oracle.mbd_counts(X, tg, 2)).all()
-    monkeypatch.setenv("SD_RANK_ROWS_PER_BATCH", "2")
+    with xcheck(SD_RANK_ROWS_PER_BATCH="7"):
+        for J in (2, 3, 4):
+            assert (eng.mbd_counts(X, None, J, algo="rank") == oracle.mbd_counts(X, None, J)).all()
+        tg = np.array([3, 699, 0, 350])
+        assert (eng.mbd_counts(X, tg, 2, algo="rank") == oracle.mbd_counts(X, tg, 2)).all()
     Xb = rng.normal(size=(5, 17000))
-    assert (eng.mbd_counts(Xb, None, 2, algo="rank") == oracle.mbd_counts(Xb, None, 2)).all()
+    with xcheck(SD_RANK_ROWS_PER_BATCH="2"):
+        assert (eng.mbd_counts(Xb, None, 2, algo="rank") == oracle.mbd_counts(Xb, None, 2)).all()
 
 
 
@@ -631,7 +629,7 @@ def test_big_n_tie_rows(eng, oracle):
         assert (eng.mbd_counts(X, None, J, algo="rank")[tg] == oracle.mbd_counts(X, tg, J)).all(), J
 
 
-def test_big_n_routes(eng, oracle, monkeypatch):
+def test_big_n_routes(eng, oracle, xcheck):
     """n > 16384: value-bucket route (default), its overflow fallback (a row where most values tie cannot be cut
     into buckets of 8192) and the chunked route forced for every row: identical integers."""
     rng = np.random.default_rng(2024)
@@ -644,9 +642,9 @@ def test_big_n_routes(eng, oracle, monkeypatch):
     X[3, 6] = -np.inf
     want = oracle.mbd_counts(X, None, 2)
     assert (eng.mbd_counts(X, None, 2, algo="rank") == want).all()
-    monkeypatch.setenv("SD_BIG_IMPL", "1")
-    assert (eng.mbd_counts(X, None, 2, algo="rank") == want).all()
-    monkeypatch.delenv("SD_BIG_IMPL")
+    for switch in ({"SD_BIG_IMPL": "1"}, {"SD_BIG_SORT": "1"}, {"SD_BIG_PART1": "1"}):
+        with xcheck(**switch):
+            assert (eng.mbd_counts(X, None, 2, algo="rank") == want).all(), switch
     tg = np.array([0, 29999, 12345, 7])
     assert (eng.mbd_counts(X, tg, 3, algo="rank") == oracle.mbd_counts(X, tg, 3)).all()
 
@@ -667,7 +665,7 @@ def _simplex_cloud(rng, n, d, kind):
 
 
 @pytest.mark.parametrize("d", [5, 6, 7, 8])
-def test_simplex_high_d_exhaustive_vs_oracle(eng, oracle, monkeypatch, d):
+def test_simplex_high_d_exhaustive_vs_oracle(eng, oracle, xcheck, d):
     """simplex_kernel_fast<5..8> (BASELINE config 4's d = 8 instantiation among them): exhaustive enumeration at small
     n against the oracle and against the generic kernel, for point clouds and for multivariate curves."""
     rng = np.random.default_rng(100 + d)
@@ -677,9 +675,8 @@ def test_simplex_high_d_exhaustive_vs_oracle(eng, oracle, monkeypatch, d):
         want = oracle.pointcloud_simplex_counts(P)
         got = eng.pointcloud_simplex_counts(P)
         assert (got == want).all(), (d, kind)
-        monkeypatch.setenv("SD_SIMPLEX_GENERIC", "1")
-        assert (eng.pointcloud_simplex_counts(P) == want).all(), (d, kind, "generic kernel")
-        monkeypatch.delenv("SD_SIMPLEX_GENERIC")
+        with xcheck(SD_SIMPLEX_GENERIC="1"):
+            assert (eng.pointcloud_simplex_counts(P) == want).all(), (d, kind, "generic kernel")
         assert want[0] > 0, (d, kind)
     # curves that keep their relative position over time (strict containment happens) plus one wandering feature
     C = rng.normal(size=(d + 6, 1, d)) + 1e-3 * rng.normal(size=(d + 6, 4, d))
@@ -695,7 +692,7 @@ def test_simplex_high_d_exhaustive_vs_oracle(eng, oracle, monkeypatch, d):
 
 
 @pytest.mark.parametrize("d", [5, 6, 7, 8])
-def test_simplex_high_d_sampled_vs_oracle(eng, oracle, monkeypatch, d):
+def test_simplex_high_d_sampled_vs_oracle(eng, oracle, xcheck, d):
     """The seeded subset sampler at d = 5..8, kernel == CPU restatement draw for draw (fast and generic kernels)."""
     rng = np.random.default_rng(200 + d)
     P = rng.normal(size=(60, d)) * rng.uniform(0.5, 2.0, size=d)
@@ -709,10 +706,9 @@ def test_simplex_high_d_sampled_vs_oracle(eng, oracle, monkeypatch, d):
     for relax in (True, False):
         want = oracle.simplex_sampled(C, tg, relax=relax, samples=200, seed=11)
         assert (eng.multi_simplex_counts(C, tg, relax=relax, samples=200, seed=11) == want).all(), (d, relax)
-    monkeypatch.setenv("SD_SIMPLEX_GENERIC", "1")
     want = oracle.simplex_sampled(C, tg, relax=True, samples=200, seed=11)
-    assert (eng.multi_simplex_counts(C, tg, relax=True, samples=200, seed=11) == want).all()
-    monkeypatch.delenv("SD_SIMPLEX_GENERIC")
+    with xcheck(SD_SIMPLEX_GENERIC="1"):
+        assert (eng.multi_simplex_counts(C, tg, relax=True, samples=200, seed=11) == want).all()
     assert want[:4].sum() > 0
 
 

@@ -36,6 +36,32 @@ def test_library_exports_every_declared_symbol(built):
     assert sorted(built.SIGNATURES) == declared
 
 
+def test_product_library_has_no_crosscheck_code(built):
+    """The product library is built without -DSD_CROSSCHECK: it says so, it does not contain the retired kernel
+    generations, and the package never opens the cross-check build (tests do, through conftest.xcheck)."""
+    import ctypes
+    import subprocess
+    prod = ctypes.CDLL(built.LIB_PATH)
+    xchk = ctypes.CDLL(built.XCHECK_LIB_PATH)
+    assert prod.sd_is_crosscheck_build() == 0 and xchk.sd_is_crosscheck_build() == 1
+    for name in _declared_symbols():
+        assert hasattr(xchk, name)
+    retired = ("rank_packed_kernel", "rank_search_kernel", "launch_mbd_rank_v1", "bucket_packed_kernel",
+               "bucket_partition_kernel")
+    syms = {p: subprocess.run(["nm", "-C", p], capture_output=True, text=True).stdout for p in (built.LIB_PATH, built.XCHECK_LIB_PATH)}
+    for r in retired:
+        assert not re.search(rf"\b{r}\b", syms[built.LIB_PATH]), f"{r} is in the product library"
+        assert re.search(rf"\b{r}\b", syms[built.XCHECK_LIB_PATH]), f"{r} missing from the cross-check library"
+    assert "getenv" not in subprocess.run(["nm", "-D", "-u", built.LIB_PATH], capture_output=True, text=True).stdout, \
+        "the product library reads no environment variable"
+    pkg = ""
+    for dp, _, fns in os.walk(os.path.join(ROOT, "statdepth_amd")):
+        for fn in fns:
+            if fn.endswith(".py") and fn != "_native.py":
+                pkg += open(os.path.join(dp, fn)).read()
+    assert "XCHECK_LIB_PATH" not in pkg and "xcheck" not in pkg
+
+
 def test_abi_version_and_error_string(built):
     lib = built.load()
     assert lib.sd_abi_version() == 1

@@ -52,6 +52,18 @@ def test_closed_form_equals_literal_enumeration(oracle, name):
     assert (a == b).all()
 
 
+@pytest.mark.parametrize("name", [n for n in golden_names(kind="univariate") if load_golden(n)["call"]["relax"]])
+def test_rank_sort_formulation_equals_closed_form(oracle, name):
+    """oracle_mbd_counts_ranksort (per-timepoint sort; bench.py's like-for-like CPU baseline of the rank kernels) gives
+    the integers of the pairwise closed form on every relax fixture, ties / NaN / +-inf included."""
+    fx = load_golden(name)
+    X = frame_values(fx["input"])
+    for J in (2, 3):
+        if J < X.shape[1]:
+            assert (oracle.mbd_counts_ranksort(X, J) == oracle.mbd_counts(X, None, J)).all()
+            assert (oracle.mbd_counts_ranksort(np.asfortranarray(X), J) == oracle.mbd_counts(X, None, J)).all()
+
+
 @pytest.mark.parametrize("name", [n for n in golden_names(kind="univariate")
                                   if not load_golden(n)["call"]["relax"]
                                   and load_golden(n)["call"]["J"] == 2
