@@ -42,9 +42,11 @@ def pmc_traffic(kernels, n, T, J):
         with open(path) as f:
             doc = json.load(f)
         ks = doc.get("kernels", {})
+        if doc.get("workload", "10000x1000") != "10000x1000":
+            continue
         got = [d["hbm_bytes_per_launch_corrected"] for name, d in ks.items()
                if any(k in name for k in kernels) and "hbm_bytes_per_launch_corrected" in d]
-        if got and doc.get("workload", "10000x1000") == "10000x1000" and len(got) >= len(kernels):
+        if len(got) >= len(kernels):
             return float(sum(got)), os.path.relpath(path, ROOT)
     return None, None
 
@@ -293,8 +295,6 @@ def main():
         used = "rank" if (args.algo == "rank" or (args.algo == "auto" and J <= 3)) else "pairwise"
         if used == "pairwise":
             kerns = ["mbd_pairwise_kernel"]
-        elif n <= 10240 and n > 1024 and J == 2:
-            kerns = ["rank_bitmap_kernel", "rank_bucket_kernel", "rank_finalize"]
         elif n <= 16384:
             kerns = ["rank_bucket_kernel", "rank_finalize"]
         else:

@@ -1,4 +1,4 @@
-"""Multi-GPU band depth: one process per GPU, targets sharded, one exchange step.
+"""Multi-GPU band depth: one process per GPU, curves owned by blocks, one exchange step.
 
 Targets are independent (the reference's outer loops carry no state, _functional.py:74,
 _pointcloud.py:45), so rank r owns a block of curves, contributes it to an all-gather
@@ -18,6 +18,35 @@ def _dist():
     return dist
 
 
+_DTYPE_CODES = {"torch.float64": 1, "torch.float32": 2, "torch.float16": 3, "torch.bfloat16": 4}
+
+
+def block_sizes(X_loc, group=None, sizes=None):
+    """Per-rank curve-block sizes of a column-sharded data set, with the consistency every exchange below relies on.
+
+    One small all-gather of (n_loc, T, dtype): ranks that disagree on the number of timepoints or the dtype would make
+    the all-to-all / all-gather split sizes disagree, which hangs or fails deep inside RCCL -- here it is a ValueError on
+    every rank.  Callers that know the partition pass `sizes` and skip the exchange (and its host synchronisation).
+    """
+    import torch
+    dist = _dist()
+    world = dist.get_world_size(group)
+    if sizes is not None:
+        sizes = [int(v) for v in sizes]
+        if len(sizes) != world or sizes[dist.get_rank(group)] != X_loc.shape[1]:
+            raise ValueError(f"sizes={sizes} does not describe this rank's block of {X_loc.shape[1]} curves")
+        return sizes
+    mine = torch.tensor([X_loc.shape[1], X_loc.shape[0], _DTYPE_CODES.get(str(X_loc.dtype), 0)], dtype=torch.int64,
+                        device=X_loc.device)
+    allv = torch.zeros(world * 3, dtype=torch.int64, device=X_loc.device)
+    dist.all_gather_into_tensor(allv, mine, group=group)
+    allv = allv.view(world, 3).cpu().tolist()
+    if len({(int(t), int(c)) for _, t, c in allv}) != 1:
+        raise ValueError("ranks disagree on the number of timepoints or the dtype of their curve blocks: "
+                         + ", ".join(f"rank {r}: T={int(t)} dtype code {int(c)}" for r, (_, t, c) in enumerate(allv)))
+    return [int(v[0]) for v in allv]
+
+
 def _default_compute(X_all, targets, J, algo):
     """HIP path: totals of the contiguous target block within the gathered matrix (device tensors)."""
     return engine.mbd_counts_range(X_all, int(targets[0]), len(targets), J=J, algo=algo, return_tensor=True)
@@ -34,13 +63,7 @@ def gather_curve_blocks(X_loc, group=None, sizes=None):
     dist = _dist()
     world = dist.get_world_size(group)
     T, n_loc = X_loc.shape
-    if sizes is None:
-        szt = torch.zeros(world, dtype=torch.int64, device=X_loc.device)
-        mine = torch.tensor([n_loc], dtype=torch.int64, device=X_loc.device)
-        dist.all_gather_into_tensor(szt, mine, group=group)
-        sizes = szt.cpu().tolist()
-    sizes = [int(v) for v in sizes]
-    assert len(sizes) == world and sizes[dist.get_rank(group)] == n_loc
+    sizes = block_sizes(X_loc, group, sizes)
     offsets = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
     if min(sizes) == max(sizes):
         # equal blocks: gather the time-major blocks as they lie, then one strided copy lays the rows out
@@ -95,16 +118,24 @@ def exchange_to_time_slices(X_loc, sizes, group=None, chunk=0, chunks=1, async_o
     bounds = [_chunk_bounds(cnt[s], chunks) for s in range(world)]
     rows_to = [bounds[s][chunk + 1] - bounds[s][chunk] for s in range(world)]     # rows this rank sends to s
     t_me = rows_to[rank]
-    if chunks == 1:
-        send = X_loc.contiguous().view(-1)                   # rows of destination s are contiguous
-    else:                                                    # stage the sub-slices of all destinations back to back
-        send = torch.cat([X_loc[toff[s] + bounds[s][chunk]: toff[s] + bounds[s][chunk + 1]] for s in range(world)],
-                         dim=0).contiguous().view(-1)
     in_split = [rows_to[s] * n_loc for s in range(world)]
     out_split = [t_me * int(sizes[r]) for r in range(world)]
     recv = torch.empty(int(sum(out_split)), dtype=X_loc.dtype, device=X_loc.device)
-    work = dist.all_to_all_single(recv, send, output_split_sizes=out_split, input_split_sizes=in_split, group=group,
-                                  async_op=async_op)
+    X_loc = X_loc.contiguous()
+    if chunks > 1 and dist.get_backend(group) == "nccl":
+        # the rows for destination s are one contiguous range of this rank's (time-major) block: RCCL takes them where
+        # they lie, one send per destination, no staging copy
+        send = [X_loc[toff[s] + bounds[s][chunk]: toff[s] + bounds[s][chunk + 1]].reshape(-1) for s in range(world)]
+        outs = list(torch.split(recv, out_split))
+        work = dist.all_to_all(outs, send, group=group, async_op=async_op)
+    else:
+        if chunks == 1:
+            send = X_loc.view(-1)                            # rows of destination s are contiguous
+        else:                                                # gloo: stage the sub-slices of all destinations back to back
+            send = torch.cat([X_loc[toff[s] + bounds[s][chunk]: toff[s] + bounds[s][chunk + 1]] for s in range(world)],
+                             dim=0).contiguous().view(-1)
+        work = dist.all_to_all_single(recv, send, output_split_sizes=out_split, input_split_sizes=in_split, group=group,
+                                      async_op=async_op)
     n = int(offsets[-1])
 
     def finish():
@@ -132,7 +163,8 @@ def _default_compute_all(X_rows, J, algo):
     return engine.mbd_counts(X_rows, None, J=J, algo=algo, return_tensor=True)
 
 
-def sharded_mbd_counts_time(X_loc, J=2, algo="auto", group=None, sizes=None, _compute_all=None, chunks=None):
+def sharded_mbd_counts_time(X_loc, J=2, algo="auto", group=None, sizes=None, _compute_all=None, chunks=None,
+                            _force_exchange=False):
     """Time-sharded form of the same totals (the right decomposition for the rank kernels).
 
     The rank formulation sorts whole rows, so splitting the TARGETS would make every GPU sort every
@@ -145,11 +177,13 @@ def sharded_mbd_counts_time(X_loc, J=2, algo="auto", group=None, sizes=None, _co
     dist = _dist()
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     T, n_loc = X_loc.shape
-    if sizes is None:
-        szt = torch.zeros(world, dtype=torch.int64, device=X_loc.device)
-        dist.all_gather_into_tensor(szt, torch.tensor([n_loc], dtype=torch.int64, device=X_loc.device), group=group)
-        sizes = szt.cpu().tolist()
-    sizes = [int(v) for v in sizes]
+    compute = _compute_all or _default_compute_all
+    if world == 1 and not _force_exchange:
+        # a single rank owns every curve at every timepoint: there is nothing to exchange and nothing to reduce
+        # (_force_exchange: tests run the collectives on one rank)
+        pk = compute(X_loc.contiguous(), J, algo)
+        return pk if isinstance(pk, torch.Tensor) else torch.as_tensor(np.asarray(pk), device=X_loc.device)
+    sizes = block_sizes(X_loc, group, sizes)
     offsets = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
     n = int(offsets[-1])
     # The exchange is cut into K sub-slices of every rank's time slice; sub-slice k+1 travels (RCCL's stream) while
@@ -158,7 +192,6 @@ def sharded_mbd_counts_time(X_loc, J=2, algo="auto", group=None, sizes=None, _co
     cnt, _ = _time_slices(T, world)
     K = chunks if chunks is not None else int(os.environ.get("SD_DIST_CHUNKS", "2"))
     K = max(1, min(K, min(cnt)))
-    compute = _compute_all or _default_compute_all
     part = None
     pending = exchange_to_time_slices(X_loc, sizes, group, 0, K, async_op=True)
     for k in range(K):
@@ -182,7 +215,7 @@ def sharded_mbd_counts_time(X_loc, J=2, algo="auto", group=None, sizes=None, _co
 
 
 def sharded_mbd_counts(X_loc, J=2, algo="auto", group=None, gather_result=False, sizes=None, mode="auto",
-                       _compute=None, _compute_all=None):
+                       _compute=None, _compute_all=None, _force_exchange=False):
     """MBD containment totals of this rank's curves against the union of all ranks' curves.
 
     mode: "targets" (all-gather of curve blocks, each rank computes its own targets: the pairwise
@@ -200,12 +233,9 @@ def sharded_mbd_counts(X_loc, J=2, algo="auto", group=None, gather_result=False,
     if mode == "auto":
         mode = "time" if (J <= 3 and algo != "pairwise" and X_loc.shape[0] >= world) else "targets"
     if mode == "time":
-        if sizes is None:
-            szt = torch.zeros(world, dtype=torch.int64, device=X_loc.device)
-            dist.all_gather_into_tensor(szt, torch.tensor([X_loc.shape[1]], dtype=torch.int64, device=X_loc.device),
-                                        group=group)
-            sizes = szt.cpu().tolist()
-        local = sharded_mbd_counts_time(X_loc, J=J, algo=algo, group=group, sizes=sizes, _compute_all=_compute_all)
+        sizes = block_sizes(X_loc, group, sizes)
+        local = sharded_mbd_counts_time(X_loc, J=J, algo=algo, group=group, sizes=sizes, _compute_all=_compute_all,
+                                        _force_exchange=_force_exchange)
         offsets = np.concatenate([[0], np.cumsum([int(v) for v in sizes])]).astype(np.int64)
     else:
         X_all, offsets = gather_curve_blocks(X_loc, group, sizes)
@@ -224,6 +254,30 @@ def sharded_mbd_counts(X_loc, J=2, algo="auto", group=None, gather_result=False,
     dist.all_gather_into_tensor(recv, send, group=group)
     recv = recv.view(world, nmax, J - 1)
     return torch.cat([recv[r, :int(sizes[r])] for r in range(world)], dim=0)
+
+
+def _default_compute_strict(X_all, targets, J):
+    """HIP path: strict band depth totals of the given targets within the gathered matrix."""
+    import torch
+    return torch.as_tensor(engine.bd_strict_counts(X_all, targets, J=J), device=X_all.device)
+
+
+def sharded_bd_strict_counts(X_loc, J=2, group=None, sizes=None, _compute=None):
+    """Strict band depth (relax=False) totals of this rank's curves against the union of all ranks' curves.
+
+    The strict kernels test every pair of other curves against one target over all T timepoints (K3, O(m n^2 T / 32)):
+    the work is per TARGET, so the targets are what is split -- the reference's outer loop (_functional.py:74-75) carries
+    no state.  One all-gather of the curve blocks, then every rank runs sd_bd_strict_j_counts for its own block of
+    targets.  Returns int64 [n_loc, J-1]."""
+    import torch
+    dist = _dist()
+    rank = dist.get_rank(group)
+    X_all, offsets = gather_curve_blocks(X_loc, group, sizes)
+    targets = np.arange(offsets[rank], offsets[rank + 1], dtype=np.int64)
+    local = (_compute or _default_compute_strict)(X_all, targets, J)
+    if not isinstance(local, torch.Tensor):
+        local = torch.as_tensor(np.asarray(local), device=X_loc.device)
+    return local.reshape(len(targets), J - 1)
 
 
 def gather_point_blocks(P_loc, group=None):
@@ -271,26 +325,28 @@ def sharded_pointcloud(P_loc, containment="simplex", samples=None, seed=0, group
 
 
 def sharded_functional_depth(df_local, J=2, relax=True, algo="auto", group=None, mode="auto", _compute=None,
-                             _compute_all=None):
+                             _compute_all=None, _compute_strict=None):
     """FunctionalDepth over curves sharded by column blocks: returns this rank's depth Series.
 
-    Normalisation as the reference (_functional.py:229,253): / T / C(n, j) with n the GLOBAL number of curves.
+    Normalisation as the reference (_functional.py:229,253): relax -> / T / C(n, j), strict -> / C(n, j), with n the
+    GLOBAL number of curves.  relax=True: sharded_mbd_counts; relax=False: sharded_bd_strict_counts (targets split).
     """
     import pandas as pd
     import torch
     from scipy.special import binom
-    if not relax:
-        raise NotImplementedError("sharded path covers relax=True (modified band depth)")
-    dist = _dist()
     X = np.ascontiguousarray(df_local.to_numpy(dtype=np.float64))
-    dev = engine._device() if (_compute is None and _compute_all is None) else torch.device("cpu")
+    hooks = (_compute, _compute_all, _compute_strict)
+    dev = engine._device() if all(h is None for h in hooks) else torch.device("cpu")
     X_loc = torch.from_numpy(X).to(dev)
-    counts = sharded_mbd_counts(X_loc, J=J, algo=algo, group=group, mode=mode, _compute=_compute,
-                                _compute_all=_compute_all).cpu().numpy()
-    n_tot = torch.tensor([X.shape[1]], dtype=torch.int64, device=dev)
-    dist.all_reduce(n_tot, group=group)
-    n, T = int(n_tot.item()), X.shape[0]
+    sizes = block_sizes(X_loc, group)
+    n, T = int(sum(sizes)), X.shape[0]
+    if relax:
+        counts = sharded_mbd_counts(X_loc, J=J, algo=algo, group=group, mode=mode, sizes=sizes, _compute=_compute,
+                                    _compute_all=_compute_all).cpu().numpy().astype(np.float64) / T
+    else:
+        counts = sharded_bd_strict_counts(X_loc, J=J, group=group, sizes=sizes,
+                                          _compute=_compute_strict).cpu().numpy().astype(np.float64)
     depth = np.zeros(X.shape[1])
     for j in range(2, J + 1):
-        depth += counts[:, j - 2].astype(np.float64) / T / binom(n, j)
+        depth += counts[:, j - 2] / binom(n, j)
     return pd.Series(index=df_local.columns, data=depth)

@@ -34,6 +34,14 @@ def _oracle_compute_all(X_rows, J, algo):
     return oracle.mbd_counts(X_rows.cpu().numpy(), None, J)
 
 
+def _oracle_compute_strict(X_all, targets, J):
+    import oracle
+    X = X_all.cpu().numpy()
+    if J == 2:
+        return oracle.bd_strict_counts(X, targets)[:, None]
+    return oracle.band_enum(X, targets, J, relax=False)
+
+
 def _worker(rank, world, port, splits, J, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -59,9 +67,20 @@ def _worker(rank, world, port, splits, J, q):
         os.environ.pop("SD_DIST_CHUNKS")
         df = pd.DataFrame(X[:, lo:hi], columns=[f"c{i}" for i in range(lo, hi)])
         ser = sharded_functional_depth(df, J=J, relax=True, **hooks)
-        q.put((rank, loc.numpy(), full.numpy(), ser))
+        # strict depth: targets split, all-gather of the blocks
+        from statdepth_amd.distributed import sharded_bd_strict_counts
+        strict = sharded_bd_strict_counts(X_loc, J=J, _compute=_oracle_compute_strict)
+        ser_s = sharded_functional_depth(df, J=J, relax=False, _compute_strict=_oracle_compute_strict)
+        # ranks that disagree on T must get an error, not a hang inside the collective
+        bad = X_loc[: T - 1] if rank == 0 else X_loc
+        try:
+            sharded_mbd_counts(bad, J=J, mode="time", **hooks)
+            mismatch = "no error"
+        except ValueError as e:
+            mismatch = "ValueError" if "disagree" in str(e) else repr(e)
+        q.put((rank, loc.numpy(), full.numpy(), ser, strict.numpy(), ser_s, mismatch))
     except Exception as e:   # surface the failure instead of letting the parent time out
-        q.put((rank, repr(e), None, None))
+        q.put((rank, repr(e), None, None, None, None, None))
         raise
     finally:
         dist.destroy_process_group()
@@ -86,13 +105,55 @@ def test_sharded_equals_single(splits, J):
     X = np.round(rng.normal(size=(T, n)).cumsum(axis=0), 1)
     want = oracle.mbd_counts(X, None, J)
     wantd = oracle.univariate_depths(X, None, J=J, relax=True)
-    for rank, loc, full, ser in res:
+    want_s = oracle.bd_strict_counts(X)[:, None] if J == 2 else oracle.band_enum(X, None, J, relax=False)
+    wantd_s = oracle.univariate_depths(X, None, J=J, relax=False)
+    for rank, loc, full, ser, strict, ser_s, mismatch in res:
         assert not isinstance(loc, str), loc
         lo, hi = splits[rank], splits[rank + 1]
         assert (loc == want[lo:hi]).all()            # integer totals do not depend on the sharding
         assert (full == want).all()
         assert list(ser.index) == [f"c{i}" for i in range(lo, hi)]
         assert np.max(np.abs(ser.to_numpy() - wantd[lo:hi])) <= 1e-12
+        assert (strict == want_s[lo:hi]).all()       # strict depth, targets split
+        assert np.max(np.abs(ser_s.to_numpy() - wantd_s[lo:hi])) <= 1e-12
+        assert mismatch == "ValueError", mismatch    # unequal T across ranks is refused before any exchange
+
+
+def _single_rank_worker(port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        from statdepth_amd.distributed import sharded_mbd_counts
+        X = np.round(np.random.default_rng(3).normal(size=(11, 40)).cumsum(axis=0), 1)
+        X_loc = torch.from_numpy(X)
+        calls = []
+
+        def counting(X_rows, J, algo):
+            calls.append(tuple(X_rows.shape))
+            return _oracle_compute_all(X_rows, J, algo)
+        a = sharded_mbd_counts(X_loc, J=2, mode="time", _compute_all=counting)
+        n_direct = len(calls)
+        b = sharded_mbd_counts(X_loc, J=2, mode="time", _compute_all=counting, _force_exchange=True)
+        q.put((a.numpy(), b.numpy(), n_direct, len(calls) - n_direct, X))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_single_rank_needs_no_exchange():
+    """World size 1: one compute call on the block as it lies (no all-to-all, no reduction); the forced exchange gives
+    the same integers through the collectives."""
+    import oracle
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_single_rank_worker, args=(_free_port(), q))
+    p.start()
+    a, b, n_direct, n_forced, X = q.get(timeout=120)
+    p.join(timeout=60)
+    assert p.exitcode == 0
+    want = oracle.mbd_counts(X, None, 2)
+    assert (a == want).all() and (b == want).all()
+    assert n_direct == 1 and n_forced >= 1
 
 
 def _pc_oracle(P_all, targets, containment, samples, seed):

@@ -583,6 +583,12 @@ def test_sharded_paths_world_size_one(eng, oracle):
         want = oracle.mbd_counts(X, None, 2)
         for mode in ("time", "targets"):
             assert (sharded_mbd_counts(Xd, J=2, mode=mode).cpu().numpy() == want).all()
+        # world size 1 needs no exchange; force it so that RCCL's all-to-all / reduce-scatter run on the GPU
+        assert (sharded_mbd_counts(Xd, J=2, mode="time", _force_exchange=True).cpu().numpy() == want).all()
+        from statdepth_amd.distributed import sharded_bd_strict_counts
+        Xs = X[:, :60]
+        got = sharded_bd_strict_counts(torch.from_numpy(np.ascontiguousarray(Xs)).cuda(), J=2).cpu().numpy()
+        assert (got[:, 0] == oracle.bd_strict_counts(Xs)).all()
         P = rng.normal(size=(40, 3))
         Pd = torch.from_numpy(P).cuda()
         got, n = sharded_pointcloud(Pd, "simplex")
