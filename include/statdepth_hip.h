@@ -100,6 +100,15 @@ int sd_mbd_counts_range(const double *X, int64_t T, int64_t n, int64_t st, int64
                         int64_t target_begin, int64_t m, int J, int algo,
                         int64_t *out, void *ws, size_t ws_bytes, void *stream);
 
+/* The same totals as TWO-LIMB unsigned integers for problems whose totals do not fit int64 (sd_mbd_counts returns
+ * SD_ERR_OVERFLOW there: J >= 4 at n = 10^5, or very long T): out[(q*(J-1) + (j-2))*2 + {0,1}] = (low, high) 64 bits
+ * of sum_t contained_j.  Requires J * C(n-1, J) < 2^63 (one timepoint's count fits 64 bits); the timepoints are
+ * processed in chunks whose totals fit int64 and added with carry.  Workspace: sd_mbd_wide_workspace_bytes. */
+size_t sd_mbd_wide_workspace_bytes(int64_t T, int64_t n, int64_t st, int64_t sn, int64_t m, int J, int algo);
+int sd_mbd_counts_wide(const double *X, int64_t T, int64_t n, int64_t st, int64_t sn,
+                       const int64_t *targets, int64_t m, int J, int algo,
+                       uint64_t *out, void *ws, size_t ws_bytes, void *stream);
+
 /* Band totals of m EXTERNAL curves Q (T x m, time-major dense) with respect to the n curves of X (time-major
  * dense, st = n, sn = 1): every curve of X is an "other".  This is what the reference's homogeneity
  * coefficients do |G| times with a temporary column (homogeneity.py:101-112,125-128: append g to F, call

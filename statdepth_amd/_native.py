@@ -37,6 +37,8 @@ SIGNATURES = {
     "sd_mbd_workspace_bytes": (_sz, [_i64, _i64, _i64, _i64, _i64, _int, _int]),
     "sd_mbd_counts": (_int, [_vp, _i64, _i64, _i64, _i64, _vp, _i64, _int, _int, _vp, _vp, _sz, _vp]),
     "sd_mbd_counts_range": (_int, [_vp, _i64, _i64, _i64, _i64, _i64, _i64, _int, _int, _vp, _vp, _sz, _vp]),
+    "sd_mbd_wide_workspace_bytes": (_sz, [_i64, _i64, _i64, _i64, _i64, _int, _int]),
+    "sd_mbd_counts_wide": (_int, [_vp, _i64, _i64, _i64, _i64, _vp, _i64, _int, _int, _vp, _vp, _sz, _vp]),
     "sd_mbd_external_counts": (_int, [_vp, _i64, _i64, _vp, _i64, _int, _vp, _vp, _sz, _vp]),
     "sd_mbd_external_workspace_bytes": (_sz, [_i64, _i64, _i64, _int]),
     "sd_mbd_subset_counts": (_int, [_vp, _i64, _i64, _vp, _i64, _int, _vp, _int, _vp, _vp]),

@@ -911,7 +911,9 @@ int launch_mbd_rank_big(const double *Y, i64 T, i64 n, const i64 *targets, i64 t
     const bool rank_nosort = xswitch("SD_BIG_SORT") != 1;   // 1: packed-key sort per value bucket (predecessor)
 #endif
     auto k_bs = bucket_search_kernel;
+#ifdef SD_CROSSCHECK
     const size_t lds_bk = BkCfg::LDS_BYTES + (size_t)BK_NT * 8;
+#endif
     SD_HIP(hipFuncSetAttribute((const void *)k_cs, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BigCfg::LDS_BYTES));
     SD_HIP(hipFuncSetAttribute((const void *)k_cq, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BigCfg::LDS_BYTES));
     SD_HIP(hipFuncSetAttribute((const void *)k_sp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sp));

@@ -65,6 +65,22 @@ static int check_matrix(const double *X, i64 T, i64 n, i64 st, i64 sn, const i64
 
 static bool is_time_major_dense(i64 n, i64 st, i64 sn) { return sn == 1 && st == n; }
 
+// wide[i] (two 64-bit limbs) (+)= part[i]: the chunk totals of sd_mbd_counts_wide
+__global__ void wide_add_kernel(const u64 *__restrict__ part, i64 count, u64 *__restrict__ wide, int first) {
+    const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const u64 v = part[i];
+    if (first) {
+        wide[2 * i] = v;
+        wide[2 * i + 1] = 0;
+    } else {
+        const u64 lo = wide[2 * i] + v;
+        wide[2 * i + 1] += lo < v ? 1u : 0u;
+        wide[2 * i] = lo;
+    }
+}
+
+
 }  // namespace sd
 
 using namespace sd;
@@ -202,6 +218,53 @@ int sd_mbd_counts_range(const double *X, int64_t T, int64_t n, int64_t st, int64
                         int64_t target_begin, int64_t m, int J, int algo,
                         int64_t *out, void *ws, size_t ws_bytes, void *stream) {
     return mbd_counts_impl(X, T, n, st, sn, nullptr, target_begin, m, J, algo, out, ws, ws_bytes, stream);
+}
+
+// ---- two-limb totals: T * C(n-1, J) beyond int64 (J >= 4 at n = 10^5) -------------------------------------------
+// The kernels accumulate per-timepoint band counts (each < 2^64 by check_count_range's recurrence bound) in 64 bits;
+// here the timepoints are cut into chunks whose totals provably fit int64, every chunk runs through the ordinary path,
+// and wide_add_kernel adds the chunk's totals into (lo, hi) pairs with carry.
+size_t sd_mbd_wide_workspace_bytes(int64_t T, int64_t n, int64_t st, int64_t sn, int64_t m, int J, int algo) {
+    if (T <= 0 || n <= 0 || m < 0 || J < 2) return 0;
+    return sd_mbd_workspace_bytes(T, n, st, sn, m, J, algo) + align_up((size_t)m * (J - 1) * 8, 256) + 256;
+}
+
+int sd_mbd_counts_wide(const double *X, int64_t T, int64_t n, int64_t st, int64_t sn,
+                       const int64_t *targets, int64_t m, int J, int algo,
+                       uint64_t *out, void *ws, size_t ws_bytes, void *stream) {
+    int rc = check_matrix(X, T, n, st, sn, targets, m);
+    if (rc) return rc;
+    if (!out) return fail(SD_ERR_INVALID, "out is null");
+    if (J < 2 || J > JMAX_HOST) return fail(SD_ERR_INVALID, "J=%d outside [2,%d]", J, JMAX_HOST);
+    if (m == 0) return SD_OK;
+    // rows per chunk: the largest Tc with Tc * C(n-1, J) < 2^63 (check_count_range's own condition)
+    u64 c;
+    if (!binom_u64_checked((u64)(n - 1), J, &c))
+        return fail(SD_ERR_OVERFLOW, "C(n-1,J) itself overflows 64 bits (n=%lld, J=%d): beyond two-limb totals too",
+                    (long long)n, J);
+    i64 Tc = c ? (i64)((((u64)1 << 63) - 1) / c) : T;
+    if (Tc > T) Tc = T;
+    while (Tc > (i64)J && check_count_range(Tc, n, J) != SD_OK) --Tc;      // the check uses max(T, J) rows
+    if (Tc < 1 || check_count_range(Tc, n, J) != SD_OK)
+        return fail(SD_ERR_OVERFLOW, "J*C(n-1,J) >= 2^63 (n=%lld, J=%d): a single chunk of timepoints does not fit int64",
+                    (long long)n, J);
+    Carver cv(ws, ws_bytes);
+    u64 *part = (u64 *)cv.take((size_t)m * (J - 1) * 8);
+    const size_t inner = sd_mbd_workspace_bytes(Tc, n, st, sn, m, J, algo);
+    void *iws = cv.take(inner);
+    if (!part || !iws) return fail(SD_ERR_WORKSPACE, "workspace too small (sd_mbd_wide_workspace_bytes)");
+    hipStream_t s = (hipStream_t)stream;
+    const i64 count = m * (J - 1);
+    for (i64 t0 = 0; t0 < T; t0 += Tc) {
+        const i64 rows = T - t0 < Tc ? T - t0 : Tc;
+        // rows [t0, t0 + rows) of either layout: x(t, i) = X[t*st + i*sn]; a curve-major block keeps its curve stride
+        if ((rc = mbd_counts_impl(X + t0 * st, rows, n, st, sn, targets, 0, m, J, algo, (int64_t *)part, iws, inner, stream)))
+            return rc;
+        hipLaunchKernelGGL(wide_add_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, part, count,
+                           (u64 *)out, t0 == 0 ? 1 : 0);
+        SD_HIP(hipGetLastError());
+    }
+    return SD_OK;
 }
 
 int sd_mbd_external_counts(const double *X, int64_t T, int64_t n, const double *Q, int64_t m, int J,

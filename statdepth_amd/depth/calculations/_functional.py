@@ -6,6 +6,7 @@ Mirrors statdepth/depth/calculations/_functional.py: `_functionaldepth` (:17-97)
 calls into libstatdepth_hip (statdepth_amd.engine); the float normalisers stay here,
 in fp64, written as the reference writes them.
 """
+import math
 from itertools import combinations
 from typing import List, Union
 
@@ -14,6 +15,7 @@ import pandas as pd
 from scipy.special import binom
 
 from ... import engine
+from ..._native import SD_ERR_OVERFLOW, StatdepthHipError
 from ._containment import _select_containment
 from ._helper import DepthDegeneracy, _handle_depth_errors
 
@@ -51,7 +53,18 @@ def _univariate_depths(df: pd.DataFrame, cols, J: int, relax: bool, device=None,
     T, n = X.shape
     tg = _positions(df, cols)
     if relax:
-        counts = engine.mbd_counts(X, tg, J=J, algo=algo, device=device).astype(np.float64) / T
+        try:
+            counts = engine.mbd_counts(X, tg, J=J, algo=algo, device=device).astype(np.float64) / T
+        except StatdepthHipError as e:
+            if e.code != SD_ERR_OVERFLOW:
+                raise
+            # T * C(n-1, J) beyond int64 (J >= 4 with ~10^5 curves): two-limb totals, exact big-integer normalisation
+            wide = engine.mbd_counts_wide(X, tg, J=J, algo=algo, device=device)
+            depth = np.zeros(len(tg), dtype=np.float64)
+            for j in range(2, J + 1):
+                den = T * math.comb(n, j)
+                depth += np.array([int(v) / den for v in wide[:, j - 2]], dtype=np.float64)     # (:253), exact quotient
+            return depth
     else:
         if J > 4:
             raise NotImplementedError('strict band depth (relax=False) is implemented for J <= 4')

@@ -113,6 +113,29 @@ def mbd_counts(X, targets=None, J=2, algo="auto", device=None, return_tensor=Fal
     return out.cpu().numpy()
 
 
+def mbd_counts_wide(X, targets=None, J=2, algo="auto", device=None):
+    """object[m, J-1] of Python ints: the totals of mbd_counts beyond int64 (sd_mbd_counts_wide, two 64-bit limbs)."""
+    t = torch()
+    lib = _native.require_device()
+    M = to_device_matrix(X, device)
+    dev = M.device
+    td, m, tp = _targets_dev(targets, M.n, dev)
+    a = ALGOS[algo] if isinstance(algo, str) else int(algo)
+    out = t.zeros((m, J - 1, 2), dtype=t.int64, device=dev)
+    if m:
+        wsb = lib.sd_mbd_wide_workspace_bytes(M.T, M.n, M.st, M.sn, m, J, a)
+        ws = t.empty(max(int(wsb), 8), dtype=t.uint8, device=dev)
+        with t.cuda.device(dev):
+            check(lib.sd_mbd_counts_wide(M.tensor.data_ptr(), M.T, M.n, M.st, M.sn, tp, m, J, a,
+                                         out.data_ptr(), ws.data_ptr(), wsb, _stream_ptr(dev)))
+    limbs = out.cpu().numpy().astype(np.uint64)
+    res = np.empty((m, J - 1), dtype=object)
+    for q in range(m):
+        for j in range(J - 1):
+            res[q, j] = (int(limbs[q, j, 1]) << 64) | int(limbs[q, j, 0])
+    return res
+
+
 def mbd_counts_range(X, target_begin, m, J=2, algo="auto", device=None, return_tensor=False):
     """Totals for the contiguous target block [target_begin, target_begin + m) (sd_mbd_counts_range)."""
     t = torch()

@@ -929,3 +929,51 @@ def test_duplicate_column_labels_are_refused():
                 FunctionalDepth([df], to_compute=tc, relax=relax)
     with pytest.raises(ValueError, match="unique"):
         FunctionalDepth([df], K=2, relax=True)
+
+
+# ---------------------------------------------------------------- totals beyond int64
+def _wide_reference(X, targets, J):
+    """Python big-integer restatement of the closed form (no NaN): sum_t C(n-1,j) - C(A,j) - C(B,j)."""
+    import math
+    T, n = X.shape
+    out = []
+    for q in targets:
+        x = X[:, q]
+        A = (X > x[:, None]).sum(axis=1)
+        B = (X < x[:, None]).sum(axis=1)
+        out.append([sum(math.comb(n - 1, j) - math.comb(int(a), j) - math.comb(int(b), j) for a, b in zip(A, B))
+                    for j in range(2, J + 1)])
+    return out
+
+
+def test_wide_totals_beyond_int64(eng, oracle):
+    """sd_mbd_counts returns SD_ERR_OVERFLOW when T * C(n-1, J) >= 2^63; sd_mbd_counts_wide computes the totals as two
+    64-bit limbs (timepoints in chunks that fit int64, added with carry), and FunctionalDepth falls through to it."""
+    import math
+    from statdepth_amd import FunctionalDepth
+    from statdepth_amd._native import StatdepthHipError, SD_ERR_OVERFLOW
+    rng = np.random.default_rng(19)
+    T, n, J = 30, 3000, 6                                   # C(2999, 6) ~ 1.0e18: every chunk holds 9 timepoints
+    X = np.round(rng.normal(size=(T, n)).cumsum(axis=0), 2)
+    assert T * math.comb(n - 1, J) >= 2 ** 63 and J * math.comb(n - 1, J) < 2 ** 63
+    tg = np.array([0, 7, 1500, 2999])
+    for algo in ("pairwise", "rank"):
+        with pytest.raises(StatdepthHipError) as ei:
+            eng.mbd_counts(X, tg, J, algo=algo)
+        assert ei.value.code == SD_ERR_OVERFLOW
+        got = eng.mbd_counts_wide(X, tg, J, algo=algo)
+        want = _wide_reference(X, tg, J)
+        assert [[int(v) for v in row] for row in got] == want, algo
+        assert max(max(row) for row in want) >= 2 ** 63     # the case really needs the second limb
+        # curve-major input: the chunks are row ranges of either layout
+        assert [[int(v) for v in row] for row in eng.mbd_counts_wide(np.asfortranarray(X), tg, J, algo=algo)] == want
+    # where int64 suffices the two paths agree
+    Y = X[:6, :200]
+    small = eng.mbd_counts(Y, None, 3)
+    wide = eng.mbd_counts_wide(Y, None, 3)
+    assert (small == np.array([[int(v) for v in row] for row in wide], dtype=np.int64)).all()
+    # through the API: depth = total / T / C(n, j) with the reference's normalisers
+    df = pd.DataFrame(X)
+    d = FunctionalDepth([df], to_compute=[0, 1500], J=J, relax=True)
+    want_d = [sum(w[j - 2] / T / math.comb(n, j) for j in range(2, J + 1)) for w in _wide_reference(X, [0, 1500], J)]
+    assert_depths_close(d.to_numpy(), np.array(want_d), TOL)
