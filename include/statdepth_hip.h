@@ -222,6 +222,20 @@ int sd_multi_simplex_sampled(const double *P, int64_t n, int64_t T, int d,
                              const int64_t *targets, int64_t m, int relax, double tol,
                              int64_t samples, uint64_t seed, int64_t *out, void *stream);
 
+/* ---- K6: componentwise band containment of multivariate curves ('r2_enum') --------
+ * Fills: _r2_enum_containment (_containment.py:83-103), which the reference declares -- "treat each component in the
+ * vector valued function as a real valued function ... if all the components are contained ... the function is
+ * contained" -- and leaves as `raise NotImplementedError`; built as the predicate of _univariate_band_depth's pair
+ * loop (_functional.py:238-253), J = 2, relax=True.  P is n x T x d row-major (curve, timepoint, feature), NaN-free.
+ *   out[q] = sum_t #{pairs {a,b} of the other curves: for every feature f,
+ *                    min(a_f(t), b_f(t)) <= x_q,f(t) <= max(a_f(t), b_f(t))};   depth = out / T / C(n,2) on the host
+ * (d = 1 gives sd_mbd_counts' totals).  The strict form (contained at every t) is sd_bd_strict_j_counts over the
+ * T*d component series of each curve (st = 1, sn = T*d) and needs no entry point of its own.
+ * n <= 65535 and n*d*2 + 8*3^d bytes of LDS (config 4: 5000 curves, d = 8: 132 KB). */
+size_t sd_multi_band_workspace_bytes(int64_t n, int64_t T, int d);
+int sd_multi_band_counts(const double *P, int64_t n, int64_t T, int d, const int64_t *targets, int64_t m,
+                         int64_t *out, void *ws, size_t ws_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -39,6 +39,8 @@ def lib():
         c_ip = ctypes.POINTER(ctypes.c_int64)
         L.oracle_band_enum.argtypes = [c_dp, ctypes.c_long, ctypes.c_long, ctypes.c_long, ctypes.c_long,
                                        c_lp, ctypes.c_long, ctypes.c_int, ctypes.c_int, c_ip]
+        L.oracle_multi_band_enum.argtypes = [c_dp, ctypes.c_long, ctypes.c_long, ctypes.c_int, c_lp, ctypes.c_long,
+                                             ctypes.c_int, ctypes.c_int, c_ip]
         L.oracle_mbd_counts.argtypes = [c_dp, ctypes.c_long, ctypes.c_long, ctypes.c_long, ctypes.c_long,
                                         c_lp, ctypes.c_long, ctypes.c_int, c_ip]
         L.oracle_mbd_counts_ranksort.argtypes = [c_dp, ctypes.c_long, ctypes.c_long, ctypes.c_long, ctypes.c_long,
@@ -111,6 +113,17 @@ def band_enum(X, targets=None, J=2, relax=True):
     tg = _targets(targets, n)
     out = np.zeros((len(tg), J - 1), dtype=np.int64)
     rc = lib().oracle_band_enum(_dp(X), T, n, st, sn, _lp(tg), len(tg), J, int(bool(relax)), _ip(out))
+    assert rc == 0
+    return out
+
+
+def multi_band_enum(P, targets=None, J=2, relax=True):
+    """'r2_enum' componentwise band containment of multivariate curves P (n, T, d), literal enumeration: int64[m, J-1]."""
+    P = np.ascontiguousarray(np.asarray(P, dtype=np.float64))
+    n, T, d = P.shape
+    tg = _targets(targets, n)
+    out = np.zeros((len(tg), J - 1), dtype=np.int64)
+    rc = lib().oracle_multi_band_enum(_dp(P), n, T, d, _lp(tg), len(tg), J, int(bool(relax)), _ip(out))
     assert rc == 0
     return out
 

@@ -124,6 +124,63 @@ int oracle_band_enum(const double *X, long T, long n, long st, long sn,
 }
 
 /* --------------------------------------------------------------------------
+ * 'r2_enum' (literal)  _r2_enum_containment          _containment.py:83-103
+ * The reference declares this containment -- every component of a vector valued
+ * function treated as a real valued function, "if all the components are
+ * contained ... the function is contained" -- and leaves the body unimplemented
+ * (raise NotImplementedError).  Restated as the docstring defines it, inside the
+ * subset loop of _univariate_band_depth (_functional.py:238-253): for every
+ * j-subset of the OTHER curves, c = #{t: for every feature f the band
+ * [min, max] (skipna, inclusive) of the subset's f-th components contains the
+ * target's}.  out[q][j-2] = sum over subsets of c (relax) or of [c == T] (strict).
+ * P is n x T x d row-major.  Literal enumeration: small cases only.
+ * -------------------------------------------------------------------------- */
+int oracle_multi_band_enum(const double *P, long n, long T, int d, const long *targets, long m, int J, int relax,
+                           i64 *out) {
+    if (J < 2 || J > 8) return -1;
+    for (long q = 0; q < m; ++q) {
+        long tg = targets[q];
+        long others[n > 1 ? n - 1 : 1];
+        long no = 0;
+        for (long i = 0; i < n; ++i)
+            if (i != tg) others[no++] = i;
+        for (int j = 2; j <= J; ++j) {
+            i64 acc = 0;
+            if (no >= j) {
+                long idx[8];
+                for (int k = 0; k < j; ++k) idx[k] = k;
+                for (;;) {
+                    long c = 0;
+                    for (long t = 0; t < T; ++t) {
+                        int all = 1;
+                        for (int f = 0; f < d && all; ++f) {
+                            double mn = NAN, mx = NAN;
+                            for (int k = 0; k < j; ++k) {
+                                double v = P[(others[idx[k]] * T + t) * d + f];
+                                if (isnan(v)) continue;
+                                if (isnan(mn) || v < mn) mn = v;
+                                if (isnan(mx) || v > mx) mx = v;
+                            }
+                            double x = P[(tg * T + t) * d + f];
+                            all = (mn <= x && x <= mx);
+                        }
+                        c += all;
+                    }
+                    acc += relax ? c : (c / T);
+                    int k = j - 1;
+                    while (k >= 0 && idx[k] == no - j + k) --k;
+                    if (k < 0) break;
+                    ++idx[k];
+                    for (int l = k + 1; l < j; ++l) idx[l] = idx[l - 1] + 1;
+                }
+            }
+            out[q * (J - 1) + (j - 2)] = acc;
+        }
+    }
+    return 0;
+}
+
+/* --------------------------------------------------------------------------
  * A2 (closed form, relax=True)    SURVEY.md 8(a) A2
  * Per target i and timepoint t, over the n-1 OTHER curves:
  *   A = #strictly above, B = #strictly below, E = #equal, N = #NaN.

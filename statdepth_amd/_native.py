@@ -55,6 +55,8 @@ SIGNATURES = {
     "sd_pointcloud_simplex_counts": (_int, [_vp, _i64, _int, _vp, _i64, _dbl, _vp, _vp]),
     "sd_multi_simplex_counts": (_int, [_vp, _i64, _i64, _int, _vp, _i64, _int, _dbl, _vp, _vp]),
     "sd_pointcloud_simplex_sampled": (_int, [_vp, _i64, _int, _vp, _i64, _dbl, _i64, _u64, _vp, _vp]),
+    "sd_multi_band_workspace_bytes": (_sz, [_i64, _i64, _int]),
+    "sd_multi_band_counts": (_int, [_vp, _i64, _i64, _int, _vp, _i64, _vp, _vp, _sz, _vp]),
     "sd_multi_simplex_sampled": (_int, [_vp, _i64, _i64, _int, _vp, _i64, _int, _dbl, _i64, _u64, _vp, _vp]),
 }
 

@@ -462,6 +462,27 @@ int sd_multi_simplex_counts(const double *P, int64_t n, int64_t T, int d, const 
     return launch_multi_simplex(P, n, T, d, targets, m, relax, tol, -1, 0, (u64 *)out, (hipStream_t)stream);
 }
 
+// ---------------------------------------------------------------------------
+// K6
+// ---------------------------------------------------------------------------
+size_t sd_multi_band_workspace_bytes(int64_t n, int64_t T, int d) {
+    if (n <= 0 || T <= 0 || d <= 0) return 0;
+    return multi_band_workspace_bytes(n, T, d);
+}
+
+int sd_multi_band_counts(const double *P, int64_t n, int64_t T, int d, const int64_t *targets, int64_t m,
+                         int64_t *out, void *ws, size_t ws_bytes, void *stream) {
+    if (!P || !out) return fail(SD_ERR_INVALID, "null pointer");
+    if (n <= 0 || T <= 0) return fail(SD_ERR_INVALID, "empty input");
+    if (d < 1 || d > 8) return fail(SD_ERR_UNSUPPORTED, "componentwise band containment covers d in [1,8], got %d", d);
+    if (!targets && m != n) return fail(SD_ERR_INVALID, "targets=NULL requires m == n");
+    if (m < 0) return fail(SD_ERR_INVALID, "m < 0");
+    int rc = check_count_range(T, n, 2);
+    if (rc) return rc;
+    if (m == 0) return SD_OK;
+    return launch_multi_band(P, n, T, d, targets, m, (u64 *)out, ws, ws_bytes, (hipStream_t)stream);
+}
+
 int sd_multi_simplex_sampled(const double *P, int64_t n, int64_t T, int d, const int64_t *targets, int64_t m,
                              int relax, double tol, int64_t samples, uint64_t seed, int64_t *out, void *stream) {
     int rc = check_simplex(P, n, d, targets, m, out, false, n - 1);

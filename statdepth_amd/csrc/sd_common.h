@@ -95,6 +95,12 @@ int launch_pointcloud_simplex(const double *P, i64 n, int d, const i64 *targets,
 int launch_multi_simplex(const double *P, i64 n, i64 T, int d, const i64 *targets, i64 m, int relax,
                          double tol, i64 samples, u64 seed, u64 *out, hipStream_t s);
 
+// K6 componentwise band containment of multivariate curves (band_enum.hip)
+bool multi_band_supported(i64 n, i64 T, int d);
+size_t multi_band_workspace_bytes(i64 n, i64 T, int d);
+int launch_multi_band(const double *P, i64 n, i64 T, int d, const i64 *targets, i64 m, u64 *out, void *ws, size_t ws_bytes,
+                      hipStream_t s);
+
 // exact C(a,k) on the host in u64 with overflow detection (returns false on overflow)
 bool binom_u64_checked(u64 a, int k, u64 *out);
 

@@ -98,6 +98,34 @@ def _curves_tensor(data: List[pd.DataFrame]) -> np.ndarray:
     return np.stack([np.asarray(df.to_numpy(dtype=np.float64)) for df in data])
 
 
+def _componentwise_band_depth(data: List[pd.DataFrame], to_compute, J: int, relax: bool, device=None) -> pd.Series:
+    """Multivariate band depth with the 'r2_enum' containment the reference declares and leaves unimplemented
+    (_containment.py:83-103: every component treated as a real-valued function, contained iff all components are).
+
+    Built as `_univariate_band_depth` (:238-253) with that predicate: bands from j-subsets of the n-1 other curves,
+    sum_j S_nj / binom(n, j) with n INCLUDING the target (:229,253) -- so one feature (d = 1) gives the univariate depth.
+    relax=True, J = 2: one launch (sd_multi_band_counts, pairs counted through the 3^d state classes).  relax=False
+    (contained at every timepoint in every component) is the strict univariate depth of the T*d component series.
+    """
+    f = [i for i in range(len(data))] if to_compute is None else to_compute
+    P = _curves_tensor(data)
+    n, T, d = P.shape
+    tg = np.asarray(list(f), dtype=np.int64)
+    depth = np.zeros(len(tg), dtype=np.float64)
+    if relax:
+        if J != 2:
+            raise NotImplementedError("'r2_enum' with relax=True is implemented for J = 2")
+        depth += engine.multi_band_counts(P, tg, device=device).astype(np.float64) / T / binom(n, 2)
+    else:
+        if J > 4:
+            raise NotImplementedError('strict band depth (relax=False) is implemented for J <= 4')
+        X = P.reshape(n, T * d).T                        # rows = (timepoint, feature), columns = curves; no copy
+        counts = engine.bd_strict_counts(X, tg, J=J, device=device).astype(np.float64)
+        for j in range(2, J + 1):
+            depth += counts[:, j - 2] / binom(n, j)
+    return pd.Series(index=f, data=depth)
+
+
 def _functionaldepth(data: List[pd.DataFrame], to_compute: Union[list, pd.Index] = None, J=2, containment='r2',
                      relax=False, deep_check=False, quiet=True, device=None, algo='auto') -> pd.Series:
     _handle_depth_errors(data=data, J=J, containment=containment, relax=relax, deep_check=deep_check)
@@ -129,7 +157,7 @@ def _functionaldepth(data: List[pd.DataFrame], to_compute: Union[list, pd.Index]
         depths = counts / binom(n - 1, d + 1)            # (:278,286): n there = number of OTHERS
         return pd.Series(index=f, data=depths)
     if cdef == 'r2_enum':
-        raise NotImplementedError                        # _containment.py:83-103
+        return _componentwise_band_depth(data, to_compute, J, relax, device)
     raise NotImplementedError('custom containment callables are only supported for univariate data')
 
 

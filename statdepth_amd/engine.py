@@ -376,3 +376,23 @@ def l1_subset_depth(P, members, device=None):
     with t.cuda.device(dev):
         check(lib.sd_l1_subset_depth(Pd.data_ptr(), n, d, md.data_ptr(), nb, bs, out.data_ptr(), _stream_ptr(dev)))
     return out.cpu().numpy()
+
+
+def multi_band_counts(P, targets=None, device=None):
+    """int64[m]: sum_t #{pairs of other curves whose componentwise band contains the target at t} (sd_multi_band_counts).
+    P: (n, T, d) curves, NaN-free."""
+    t = torch()
+    lib = _native.require_device()
+    Pd, dev = _points_dev(P, 3, device)
+    n, T, d = Pd.shape
+    if bool(t.isnan(Pd).any()):
+        raise ValueError("componentwise band containment ('r2_enum') does not accept NaN values")
+    td, m, tp = _targets_dev(targets, n, dev)
+    out = t.empty(m, dtype=t.int64, device=dev)
+    if m == 0:
+        return out.cpu().numpy()
+    wsb = int(lib.sd_multi_band_workspace_bytes(n, T, d))
+    ws = t.empty(max(wsb, 8), dtype=t.uint8, device=dev)
+    with t.cuda.device(dev):
+        check(lib.sd_multi_band_counts(Pd.data_ptr(), n, T, d, tp, m, out.data_ptr(), ws.data_ptr(), wsb, _stream_ptr(dev)))
+    return out.cpu().numpy()

@@ -977,3 +977,66 @@ def test_wide_totals_beyond_int64(eng, oracle):
     d = FunctionalDepth([df], to_compute=[0, 1500], J=J, relax=True)
     want_d = [sum(w[j - 2] / T / math.comb(n, j) for j in range(2, J + 1)) for w in _wide_reference(X, [0, 1500], J)]
     assert_depths_close(d.to_numpy(), np.array(want_d), TOL)
+
+
+# ---------------------------------------------------------------- 'r2_enum': componentwise band containment
+@pytest.mark.parametrize("d", [1, 2, 3, 5, 8])
+def test_componentwise_band_vs_literal_enumeration(eng, oracle, d):
+    """sd_multi_band_counts (pairs counted through the 3^d state classes) against the literal pair enumeration, ties
+    included; d = 1 against the univariate kernels; strict form through K3 on the component series."""
+    from statdepth_amd import FunctionalDepth
+    rng = np.random.default_rng(300 + d)
+    n, T = 23, 7
+    P = np.round(rng.normal(size=(n, T, d)).cumsum(axis=1), 1)          # rounded: ties in single components
+    P[3] = P[4]                                                          # a duplicated curve
+    P[5, :, 0] = P[6, :, 0]
+    want = oracle.multi_band_enum(P, None, 2, True)[:, 0]
+    assert want.sum() > 0
+    assert (eng.multi_band_counts(P) == want).all()
+    tg = np.array([22, 0, 4])
+    assert (eng.multi_band_counts(P, tg) == want[tg]).all()
+    if d == 1:
+        assert (eng.mbd_counts(np.ascontiguousarray(P[:, :, 0].T), None, 2)[:, 0] == want).all()
+    frames = [pd.DataFrame(P[i]) for i in range(n)]
+    import math
+    got = FunctionalDepth(frames, containment="r2_enum", relax=True)
+    assert_depths_close(got.to_numpy(), want / T / math.comb(n, 2), TOL)
+    for J in (2, 3):
+        strict = FunctionalDepth(frames, J=J, containment="r2_enum", relax=False, to_compute=[0, 3, 10])
+        ws = oracle.multi_band_enum(P, [0, 3, 10], J, False)
+        wd = sum(ws[:, j - 2] / math.comb(n, j) for j in range(2, J + 1))
+        assert_depths_close(strict.to_numpy(), wd, TOL)
+    with pytest.raises(ValueError, match="NaN"):
+        Pn = P.copy(); Pn[1, 2, 0] = np.nan
+        eng.multi_band_counts(Pn)
+
+
+def test_config4_componentwise_band_full_size(eng, oracle):
+    """BASELINE.json configs[3] in its componentwise-band form (SURVEY.md 8(a) M1 alternative (iii)): 5 000 curves x 500
+    timepoints x 8 features, exact pair counts for every target; checked on a few targets against per-timepoint literal
+    counting in numpy, plus the d = 1 / monotonicity properties at full size."""
+    import torch
+    n, T, d = 5000, 500, 8
+    g = torch.Generator(device="cuda").manual_seed(1236)
+    P = torch.randn(n, T, d, dtype=torch.float64, device="cuda", generator=g).cumsum(1)
+    P[:16] *= 0.05
+    got = eng.multi_band_counts(P)
+    assert got.shape == (n,) and got.min() >= 0 and got.max() <= T * (n - 1) * (n - 2) // 2
+    Ph = P.cpu().numpy()
+    for q in (0, 7, 2500, 4999):
+        tot = 0
+        for t in range(0, T):
+            up = (Ph[:, t, :] > Ph[q, t, :]).astype(np.uint16)
+            dn = (Ph[:, t, :] < Ph[q, t, :]).astype(np.uint16)
+            w = (1 << np.arange(d)).astype(np.uint16)
+            mask = (up @ w) | ((dn @ w) << 8)
+            mask = np.delete(mask, q)
+            cnt = np.bincount(mask, minlength=65536)
+            vals = np.nonzero(cnt)[0]
+            disj = (vals[:, None] & vals[None, :]) == 0
+            ordered = int((cnt[vals][:, None] * cnt[vals][None, :] * disj).sum())
+            tot += (ordered - int(cnt[0])) // 2
+        assert int(got[q]) == tot, q
+    assert got[:16].mean() > 50 * max(1.0, got[16:].mean())     # the central curves are deep, the rest hardly ever
+    one = eng.multi_band_counts(P[:, :, :1].contiguous())
+    assert (one >= got).all()                                    # fewer features: never fewer containing pairs

@@ -162,3 +162,20 @@ def test_l1_matches_numpy_restatement(oracle):
     P[5] = P[2]
     got = oracle.l1_depth(P)
     assert np.isnan(got[5]) and np.isnan(got[2]) and np.isnan(got).sum() == 2
+
+
+def test_componentwise_band_enum_reduces_to_univariate(oracle):
+    """'r2_enum' (_containment.py:83-103, unimplemented upstream) restated literally: with ONE feature it is the
+    univariate enumeration the fixtures pin, for both relax modes, NaN included."""
+    for name in ("g1_docs_J3_relax", "g8_nan2_J3_relax", "g8_int_8x5_relax"):
+        X = frame_values(load_golden(name)["input"])
+        P = np.ascontiguousarray(X.T[:, :, None])
+        for relax in (True, False):
+            assert (oracle.multi_band_enum(P, None, 3, relax) == oracle.band_enum(X, None, 3, relax)).all()
+    # two features: contained iff contained in both -> never more than either feature alone
+    rng = np.random.default_rng(5)
+    P = np.round(rng.normal(size=(9, 6, 2)).cumsum(axis=1), 1)
+    both = oracle.multi_band_enum(P, None, 2, True)[:, 0]
+    for f in range(2):
+        alone = oracle.band_enum(np.ascontiguousarray(P[:, :, f].T), None, 2, True)[:, 0]
+        assert (both <= alone).all()
