@@ -149,6 +149,23 @@ def extras_single_gpu(torch, dev, stream, lib, check, ALGOS, oracle, reps=10):
                                                               oc.data_ptr(), stream.cuda_stream)), 3, 1, stream, torch)
     tg = np.arange(0, 500, 31)
     assert (oc.cpu().numpy()[tg] == oracle.simplex_sampled(C, tg, relax=True, samples=256, seed=1236)).all(), "simplex d=8"
+    # config 4 in its componentwise-band form ('r2_enum'): exact, every target
+    n4, T4, d4 = 5000, 500, 8
+    P4 = walks(torch, T4, n4 * d4, 1236, dev).view(T4, n4, d4).permute(1, 0, 2).contiguous()
+    o4 = torch.empty(n4, dtype=torch.int64, device=dev)
+    wsb4 = int(lib.sd_multi_band_workspace_bytes(n4, T4, d4))
+    ws4 = torch.empty(wsb4, dtype=torch.uint8, device=dev)
+    _, ms = timed(lambda _: check(lib.sd_multi_band_counts(P4.data_ptr(), n4, T4, d4, 0, n4, o4.data_ptr(), ws4.data_ptr(), wsb4,
+                                                          stream.cuda_stream)), 2, 1, stream, torch)
+    sub = P4[:, :2, :].contiguous()                                  # the oracle's literal pair enumeration on 2 timepoints
+    o2 = torch.empty(n4, dtype=torch.int64, device=dev)
+    check(lib.sd_multi_band_counts(sub.data_ptr(), n4, 2, d4, 0, n4, o2.data_ptr(), ws4.data_ptr(), wsb4, stream.cuda_stream))
+    tg = np.array([0, 1234, 4999])
+    assert (o2.cpu().numpy()[tg] == oracle.multi_band_enum(sub.cpu().numpy(), tg, 2, True)[:, 0]).all(), "r2_enum"
+    out["config4_componentwise_band"] = {"workload": "5000 curves x 500 timepoints x 8 features, componentwise band containment "
+                                         "(r2_enum), exact pair counts, all targets", "ms": ms,
+                                         "curve_pairs_per_s": float(n4) * (n4 - 1) / (ms * 1e-3), "checked_targets": len(tg)}
+    del P4, ws4
     out["simplex_sampled_d8"] = {"workload": "500 curves x 50 timepoints x 8 features, 256 subsets per target (config 4 shape)",
                                  "ms": ms, "simplex_tests_per_s": 500 * 256 * 50 / (ms * 1e-3), "checked_targets": len(tg)}
     return out
