@@ -2,9 +2,8 @@
 
 `FunctionalDepth` (:362-402) and `PointcloudDepth` (:347-359) keep the reference's
 signatures; `device=` and `algo=` are keyword-only additions.  Result classes keep
-the reference's method names and conventions (:14-65,178-185,337-341).  The plotly
-drawing helpers of the reference (:91-175,193-335) are visualisation, not part of
-the hot path, and are not provided.
+the reference's method names and conventions (:14-65,178-185,337-341), including the
+plotly views (:91-175,193-335; `_plotting.py`, host-side visualisation outside the hot path).
 """
 from typing import List
 
@@ -14,6 +13,7 @@ from abc import ABC, abstractmethod
 from .calculations._functional import _functionaldepth, _samplefunctionaldepth
 from .calculations._helper import DepthDegeneracy   # noqa: F401
 from .calculations._pointcloud import _pointwisedepth, _samplepointwisedepth
+from . import _plotting
 
 __all__ = ['FunctionalDepth', 'PointcloudDepth']
 
@@ -98,6 +98,16 @@ class _FunctionalDepthUnivariate(_FunctionalDepthSeries):
     def get_outlying_data(self, n=1) -> pd.DataFrame:
         return self._orig_data.loc[:, self.outlying(n=n).index]
 
+    def plot_deepest(self, n=1, title=None, xaxis_title=None, yaxis_title=None, return_plot=False, showlegend=False):
+        '''All curves, the n deepest in red (:141-157).'''
+        return _plotting.curves_figure(self._orig_data, self.deepest(n=n).index, title, xaxis_title, yaxis_title,
+                                       return_plot, showlegend)
+
+    def plot_outlying(self, n=1, title=None, xaxis_title=None, yaxis_title=None, return_plot=False, showlegend=False):
+        '''All curves, the n most outlying in red (:159-175).'''
+        return _plotting.curves_figure(self._orig_data, self.outlying(n=n).index, title, xaxis_title, yaxis_title,
+                                       return_plot, showlegend)
+
 
 class _PointwiseDepth(_FunctionalDepthSeries):
     '''Points are the ROWS of the frame (:337-341).'''
@@ -107,6 +117,26 @@ class _PointwiseDepth(_FunctionalDepthSeries):
 
     def get_deepest_data(self, n=1) -> pd.DataFrame:
         return self._orig_data.loc[self.deepest(n=n).index, :]
+
+    def plot_depths(self, invert_colors=False, marker=None, return_plot=False, title='', xaxis_title=None,
+                    yaxis_title=None):
+        '''Points coloured by depth (:193-243).'''
+        return _plotting.depth_coloured_figure(self._orig_data, self._depths, invert_colors, marker, return_plot, title,
+                                               xaxis_title, yaxis_title)
+
+    def plot_distribution(self, invert_colors=False, marker=None):
+        '''Alias of plot_depths, shown at once (:343-344).'''
+        return self.plot_depths(invert_colors=invert_colors, marker=marker)
+
+    def plot_deepest(self, n=1, return_plot=False, title='', xaxis_title=None, yaxis_title=None):
+        '''All points in blue, the n deepest in red (:309-321).'''
+        return _plotting.points_figure(self._orig_data, self.deepest(n=n).index, return_plot, title, xaxis_title,
+                                       yaxis_title)
+
+    def plot_outlying(self, n=1, return_plot=False, title='', xaxis_title=None, yaxis_title=None):
+        '''All points in blue, the n most outlying in red (:323-335).'''
+        return _plotting.points_figure(self._orig_data, self.outlying(n=n).index, return_plot, title, xaxis_title,
+                                       yaxis_title)
 
 
 def PointcloudDepth(data: pd.DataFrame, to_compute: pd.Index = None, K=None, containment='simplex', quiet=True,

@@ -190,3 +190,26 @@ def test_device_matrix_accepts_both_pandas_layouts():
     xc = c.to_numpy(dtype=np.float64, copy=False)
     xf = f.to_numpy(dtype=np.float64, copy=False)
     assert xc.flags.c_contiguous and (xc == xf).all()
+
+
+def test_plot_helpers_build_figures():
+    """The plotly views of the result objects (reference depth.py:91-175,193-335): figures come back with the expected
+    traces -- everything plain, the deepest / most outlying items marked -- without any device work."""
+    import plotly.graph_objects as go
+    from statdepth_amd.depth.depth import _FunctionalDepthUnivariate, _PointwiseDepth
+    rng = np.random.default_rng(1)
+    df = pd.DataFrame(rng.normal(size=(9, 6)), columns=list("abcdef"))
+    res = _FunctionalDepthUnivariate(df=df, depths=pd.Series(index=df.columns, data=[.1, .5, .3, .2, .4, .0]))
+    fig = res.plot_deepest(n=2, title="t", return_plot=True)
+    assert isinstance(fig, go.Figure) and len(fig.data) == 6
+    assert [tr.name for tr in fig.data[-2:]] == ["b", "e"] and all(tr.line.color == "Red" for tr in fig.data[-2:])
+    fig = res.plot_outlying(n=1, return_plot=True, showlegend=True)
+    assert fig.data[-1].name == "f" and fig.layout.showlegend is True
+    for d in (2, 3):
+        pc = pd.DataFrame(rng.normal(size=(12, d)))
+        pres = _PointwiseDepth(df=pc, depths=pd.Series(index=pc.index, data=rng.random(12)))
+        assert len(pres.plot_deepest(n=3, return_plot=True).data) == 2
+        assert len(pres.plot_outlying(n=3, return_plot=True).data[1].x) == 3
+        assert len(pres.plot_depths(invert_colors=True, return_plot=True).data) == 1
+    with pytest.raises(ValueError, match="Dimensionality"):
+        _PointwiseDepth(df=pc.iloc[:, :1], depths=pd.Series(index=pc.index, data=rng.random(12))).plot_depths(return_plot=True)
