@@ -179,3 +179,15 @@ def test_componentwise_band_enum_reduces_to_univariate(oracle):
     for f in range(2):
         alone = oracle.band_enum(np.ascontiguousarray(P[:, :, f].T), None, 2, True)[:, 0]
         assert (both <= alone).all()
+
+
+def test_oracle_is_sanitizer_clean():
+    """The checker itself under AddressSanitizer + UBSan on the CPU (`make -C oracle sanitize`): every entry point driven
+    on small inputs with ties, NaN and infinities; the GPU pool offers no sanitizer, so this is where memory errors in
+    the test infrastructure would show."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run(["make", "-s", "-C", os.path.join(root, "oracle"), "sanitize"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "selftest ok" in r.stdout and "ERROR" not in r.stderr

@@ -1,17 +1,24 @@
 #!/usr/bin/env python3
-"""Differential fuzz on the GPU box: second-generation strict kernels against the first generation, register-resident
+"""Differential fuzz on the GPU box: the product library's kernels against the predecessors kept in the cross-check
+library (libstatdepth_hip_xcheck.so): second-generation strict kernels against the first generation, register-resident
 simplex test against the generic one, large-n route variants.  usage: fuzz_secondary.py [cases] [seed]"""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from statdepth_amd import engine
+from statdepth_amd import engine, _native
+PRODUCT = _native.load()
+XCHECK = _native.open_library(_native.XCHECK_LIB_PATH)      # the switches below are honoured by this build only
 
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 bad = 0
 def env(k, v):
-    if v is None: os.environ.pop(k, None)
-    else: os.environ[k] = v
+    if v is None:
+        os.environ.pop(k, None)
+        if not any(e.startswith("SD_") for e in os.environ): _native._LIB = PRODUCT
+    else:
+        os.environ[k] = v
+        _native._LIB = XCHECK
 for c in range(cases):
     # ---- strict band depth ----
     n = int(rng.choice([rng.integers(3, 70), rng.integers(70, 600), rng.integers(600, 1500)]))
