@@ -152,7 +152,10 @@ __global__ __launch_bounds__(BIG_NT) void chunk_search_kernel(const double *__re
 // =====================================================================================================
 constexpr int BK_NT = 512, BK_E = 16;
 constexpr int BK_C = BK_NT * BK_E;             // bucket capacity 8192
-constexpr int BK_FILL = 5500;                  // target mean fill
+#ifndef SD_BK_FILL
+#define SD_BK_FILL 5500
+#endif
+constexpr int BK_FILL = SD_BK_FILL;            // target mean fill
 constexpr int BK_MAXNB = 1024;
 using BkCfg = R2Cfg<BK_NT, BK_E>;
 

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Development check of the bucket rank kernel (SD_RANK_IMPL=4) on the GPU box: equality with the packed-sort
-path (SD_RANK_IMPL=3) on whole matrices and with the CPU oracle on a target sample; device time per call."""
+"""Development check of the bucket rank kernel (the product library's default) on the GPU box: equality with the
+packed-sort path (SD_RANK_IMPL=3 in the cross-check library) on whole matrices and with the CPU oracle on a target
+sample; device time per call."""
 import os
 import sys
 import time
@@ -10,13 +11,21 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import oracle
-from statdepth_amd import engine
+torch.cuda.init()
+from statdepth_amd import engine, _native
+PRODUCT = _native.load()
+XCHECK = _native.open_library(_native.XCHECK_LIB_PATH)
 
 oracle.build()
 
 
 def run(X, J, impl, reps=0):
-    os.environ["SD_RANK_IMPL"] = str(impl)
+    if impl == 4:
+        os.environ.pop("SD_RANK_IMPL", None)
+        _native._LIB = PRODUCT
+    else:
+        os.environ["SD_RANK_IMPL"] = str(impl)
+        _native._LIB = XCHECK
     Xd = engine.to_device_matrix(X)
     out = engine.mbd_counts(Xd, None, J, algo="rank")
     ms = None

@@ -5,6 +5,8 @@ simplex test against the generic one, large-n route variants.  usage: fuzz_secon
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+torch.cuda.init()                                             # the runtime is up before a second HIP library is opened
 from statdepth_amd import engine, _native
 PRODUCT = _native.load()
 XCHECK = _native.open_library(_native.XCHECK_LIB_PATH)      # the switches below are honoured by this build only
