@@ -225,6 +225,8 @@ def main():
     ap.add_argument("--mode", default="auto", choices=["auto", "time", "targets"], help="multi-GPU decomposition")
     ap.add_argument("--force-dist", action="store_true",
                     help="run the torch.distributed path even at world size 1 (exercises RCCL on one GPU)")
+    ap.add_argument("--extras-multi", action="store_true",
+                    help="with --force-dist: also run the multi-GPU extras (configs 3 and 5 through the sharded paths) at world size 1")
     args = ap.parse_args()
 
     import torch
@@ -305,9 +307,13 @@ def main():
 
     result_sum = int(outs[0].sum().item())
     extras = None
+    extras_error = None
     if not args.no_extras and args.variant == "walk" and (n_loc, T, J) == (10000, 1000, 2):
-        if N > 1:
-            extras = extras_multi_gpu(torch, dist, dev, rank, N)
+        if N > 1 or (use_dist and args.extras_multi):
+            try:                                         # a failing secondary leg must not cost the headline its line
+                extras = extras_multi_gpu(torch, dist, dev, rank, N)
+            except Exception as e:                       # noqa: BLE001
+                extras_error = f"{type(e).__name__}: {e}"
     if rank == 0:
         used = "rank" if (args.algo == "rank" or (args.algo == "auto" and J <= 3)) else "pairwise"
         if used == "pairwise":
@@ -372,11 +378,16 @@ def main():
                 "sample": f"oracle_mbd_counts_ranksort (C, OpenMP): the GPU's own O(n T log n) rank formulation, all {n_loc} "
                           f"targets, {cpu_dt2:.2f} s -- the like-for-like CPU number",
             }
-            if not args.no_extras and args.variant == "walk" and (n_loc, T, J) == (10000, 1000, 2):
+            if not args.no_extras and not use_dist and args.variant == "walk" and (n_loc, T, J) == (10000, 1000, 2):
                 del mats[1:], outs[1:]
-                extras = extras_single_gpu(torch, dev, stream, lib, check, ALGOS, oracle)
+                try:
+                    extras = extras_single_gpu(torch, dev, stream, lib, check, ALGOS, oracle)
+                except Exception as e:                   # noqa: BLE001
+                    extras_error = f"{type(e).__name__}: {e}"
         if extras:
             line["extras"] = extras
+        if extras_error:
+            line["extras_error"] = extras_error
         print(json.dumps(line), flush=True)
     if use_dist:
         dist.destroy_process_group()
