@@ -243,7 +243,20 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29531")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        # RCCL prints a version banner on STDOUT when its first communicator comes up; the contract is ONE JSON line there,
+        # so stdout points at stderr until the communicator exists
+        sys.stdout.flush()
+        keep = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+            torch.cuda.set_device(local)
+            dist.barrier()
+            torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(keep, 1)
+            os.close(keep)
     N = world
     assert args.gpus == N, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     torch.cuda.set_device(local)
