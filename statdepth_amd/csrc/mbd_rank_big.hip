@@ -32,8 +32,25 @@
 
 namespace sd {
 
-struct AB2 { u32 B, A; };
-constexpr u32 AB2_NAN = 0xFFFFFFFFu;           // B field: the curve is NaN at this timepoint
+// The pair image of a batch of rows: for every (row, curve) ONE u32 -- B (others strictly below), with bit 31 set when
+// the curve ties with another one at this timepoint -- and, for the tied keys only, A (strictly above) in a second
+// image; an untied key has A = n_real - 1 - B.  Continuous data writes and reads 4 bytes per key instead of 8 (the
+// scattered 8-byte pairs were 596 MB of the ranking kernel's traffic at config 3, profiles/r02_config3_pmc_traffic.json).
+struct AB2 {
+    u32 *B;
+    u32 *A;
+};
+constexpr u32 AB2_NAN = 0xFFFFFFFFu;           // B word: the curve is NaN at this timepoint
+constexpr u32 AB2_TIE = 0x80000000u;           // B word: A is in the second image
+
+__device__ __forceinline__ void ab_store(const AB2 &ab, size_t idx, u32 B, u32 A, u32 nreal) {
+    if (A + B + 1u == nreal) {
+        ab.B[idx] = B;
+    } else {
+        ab.B[idx] = B | AB2_TIE;
+        ab.A[idx] = A;
+    }
+}
 
 // =====================================================================================================
 // route 2: chunks in curve order
@@ -85,7 +102,7 @@ __global__ __launch_bounds__(BIG_NT) void chunk_search_kernel(const double *__re
                                                               i64 rows, const double *__restrict__ sorted,
                                                               i64 sstride, const u32 *__restrict__ nanrow,
                                                               int nchunks, const u32 *__restrict__ rowflag,
-                                                              AB2 *__restrict__ ab) {
+                                                              AB2 ab) {
     constexpr int E = BIG_E, WB = BigCfg::WB, N = BIG_C;
     extern __shared__ double Sm[];
     const int t = threadIdx.x;
@@ -129,19 +146,14 @@ __global__ __launch_bounds__(BIG_NT) void chunk_search_kernel(const double *__re
             }
         }
         const u32 nnan = nanrow[rb];
-        AB2 *dst = ab + rb * n + qbase + t;
+        const size_t dst = (size_t)(rb * n + qbase + t);
 #pragma unroll
         for (int e = 0; e < E; ++e) {
             if (t + e * BIG_NT < nq) {
-                AB2 v;
-                if (x[e] == x[e]) {
-                    v.B = lo[e];
-                    v.A = (x[e] == INF) ? 0u : (u32)(n - hi[e]) - nnan;
-                } else {
-                    v.B = AB2_NAN;
-                    v.A = 0;
-                }
-                dst[e * BIG_NT] = v;
+                if (x[e] == x[e])
+                    ab_store(ab, dst + e * BIG_NT, lo[e], (x[e] == INF) ? 0u : (u32)(n - hi[e]) - nnan, (u32)n - nnan);
+                else
+                    ab.B[dst + e * BIG_NT] = AB2_NAN;
             }
         }
     }
@@ -205,7 +217,7 @@ __global__ __launch_bounds__(1024) void bucket_partition_kernel(const double *__
                                                                 const double *__restrict__ spl,
                                                                 u32 *__restrict__ bcnt, u32 *__restrict__ nnanrow,
                                                                 u32 *__restrict__ ovf, double *__restrict__ bval,
-                                                                u32 *__restrict__ bidx, AB2 *__restrict__ ab, int dbg) {
+                                                                u32 *__restrict__ bidx, AB2 ab, int dbg) {
     __shared__ double s_spl[BK_MAXNB];
     __shared__ u32 s_hist[BK_MAXNB];
     __shared__ u32 s_base[BK_MAXNB];
@@ -244,10 +256,7 @@ __global__ __launch_bounds__(1024) void bucket_partition_kernel(const double *__
                 off[e] = atomicAdd(&s_hist[lo], 1u);
             } else {
                 ++mynan;
-                AB2 v;
-                v.B = AB2_NAN;
-                v.A = 0;
-                ab[rb * n + i] = v;
+                ab.B[rb * n + i] = AB2_NAN;
             }
         }
     }
@@ -284,7 +293,7 @@ __global__ __launch_bounds__(BP2_NT) void bucket_partition2_kernel(const double 
                                                                    const double *__restrict__ spl,
                                                                    u32 *__restrict__ bcnt, u32 *__restrict__ nnanrow,
                                                                    u32 *__restrict__ ovf, double *__restrict__ bval,
-                                                                   u32 *__restrict__ bidx, AB2 *__restrict__ ab) {
+                                                                   u32 *__restrict__ bidx, AB2 ab) {
     extern __shared__ double Sm2[];
     double *Skey = Sm2;                                               // [BP2_C]
     u32 *Sid = reinterpret_cast<u32 *>(Skey + BP2_C);                 // [BP2_C]
@@ -328,10 +337,7 @@ __global__ __launch_bounds__(BP2_NT) void bucket_partition2_kernel(const double 
                 off[e] = atomicAdd(&s_hist[lo], 1u);
             } else {
                 ++mynan;
-                AB2 v;
-                v.B = AB2_NAN;
-                v.A = 0;
-                ab[rb * n + i] = v;
+                ab.B[rb * n + i] = AB2_NAN;
             }
         }
     }
@@ -400,7 +406,7 @@ __global__ __launch_bounds__(BK_NT) void bucket_packed_kernel(i64 n, int NB, con
                                                               const u32 *__restrict__ ovf,
                                                               const double *__restrict__ bval,
                                                               const u32 *__restrict__ bidx, u32 *__restrict__ bflag,
-                                                              AB2 *__restrict__ ab) {
+                                                              AB2 ab) {
     using C = BkCfg;
     using K = BkKeys<BK_NT, BK_E>;
     constexpr int E = BK_E, NT = BK_NT, LN = C::LN, WB = C::WB;
@@ -476,10 +482,7 @@ __global__ __launch_bounds__(BK_NT) void bucket_packed_kernel(i64 n, int NB, con
     const u32 base = s_basecnt;
     const u32 nreal = (u32)n - nnanrow[rb];
     for (int j = t; j < cnt; j += NT) {
-        AB2 v;
-        v.B = base + R[j];
-        v.A = nreal - 1u - v.B;
-        ab[rb * n + bidx[slot0 + j]] = v;
+        ab.B[rb * n + bidx[slot0 + j]] = base + R[j];               // distinct keys: A = nreal - 1 - B
     }
 }
 #endif  // SD_CROSSCHECK
@@ -504,7 +507,7 @@ __global__ __launch_bounds__(BR_NT) void bucket_rank_kernel(i64 n, i64 rows, int
                                                             const u32 *__restrict__ ovf,
                                                             const double *__restrict__ bval,
                                                             const u32 *__restrict__ bidx, u32 *__restrict__ bflag,
-                                                            AB2 *__restrict__ ab) {
+                                                            AB2 ab) {
     constexpr int E = BR_E, NT = BR_NT, NBF = BR_NBF, NW = BR_NW, U2 = BR_U2;
     extern __shared__ double Sm[];
     double *red = Sm;                                                 // [NW][2]
@@ -566,19 +569,14 @@ __global__ __launch_bounds__(BR_NT) void bucket_rank_kernel(i64 n, i64 rows, int
         gbase = rb_readlane(rb_row_incl_scan(g), 15);
     }
     const u32 nreal = (u32)n - nnanrow[rb];
-    AB2 *abrow = ab + rb * n;
+    const size_t abrow = (size_t)(rb * n);
     const u32 *idp = bidx + slot0 + t;
     if (!(hi > lo)) {
         // every key of the bucket has the same value (or there is one key): all tied
         if (hi == lo) {
 #pragma unroll
             for (int e = 0; e < E; ++e)
-                if (t + e * NT < cnt) {
-                    AB2 v;
-                    v.B = gbase;
-                    v.A = nreal - gbase - (u32)cnt;
-                    abrow[idp[e * NT]] = v;
-                }
+                if (t + e * NT < cnt) ab_store(ab, abrow + idp[e * NT], gbase, nreal - gbase - (u32)cnt, nreal);
         } else if (t == 0) bflag[rb * NB + b] = 1u;                   // a signalling NaN poisoned the range: sort it
         return;
     }
@@ -661,12 +659,7 @@ __global__ __launch_bounds__(BR_NT) void bucket_rank_kernel(i64 n, i64 rows, int
             for (int e = 0; e < E; ++e) {
                 if (e * NT >= cnt) break;
                 const u32 base = bc[e] & 0xFFFFu, fc = bc[e] >> 16;
-                if (fc) {
-                    AB2 v;
-                    v.B = gbase + base;
-                    v.A = nreal - (gbase + base + fc);
-                    abrow[idp[e * NT]] = v;
-                }
+                if (fc) ab_store(ab, abrow + idp[e * NT], gbase + base, nreal - (gbase + base + fc), nreal);
             }
             return;
         }
@@ -704,12 +697,7 @@ __global__ __launch_bounds__(BR_NT) void bucket_rank_kernel(i64 n, i64 rows, int
                 le += (y.y <= x) ? 1u : 0u;
             }
         }
-        if (fc) {
-            AB2 v;
-            v.B = gbase + base + less;
-            v.A = nreal - (gbase + base + le);
-            abrow[idp[e * NT]] = v;
-        }
+        if (fc) ab_store(ab, abrow + idp[e * NT], gbase + base + less, nreal - (gbase + base + le), nreal);
     }
 }
 
@@ -718,7 +706,7 @@ __global__ __launch_bounds__(BK_NT) void bucket_search_kernel(i64 n, int NB, con
                                                               const u32 *__restrict__ nnanrow,
                                                               const u32 *__restrict__ bflag,
                                                               const double *__restrict__ bval,
-                                                              const u32 *__restrict__ bidx, AB2 *__restrict__ ab) {
+                                                              const u32 *__restrict__ bidx, AB2 ab) {
     using C = BkCfg;
     constexpr int E = BK_E, NT = BK_NT, LE = C::LE, WB = C::WB, N = C::N;
     extern __shared__ double Sm[];
@@ -762,11 +750,8 @@ __global__ __launch_bounds__(BK_NT) void bucket_search_kernel(i64 n, int NB, con
             step >>= 1;
             if (hi + step <= n_act && Sm[r2_phys<LE>(hi + step - 1)] <= x) hi += step;
         }
-        AB2 v;
-        v.B = base + (u32)lo;
         // values above x: everything real beyond x's tie run (x = +inf: the padding ties with it, nothing is above)
-        v.A = (x == INF) ? 0u : nreal - (base + (u32)hi);
-        ab[rb * n + bidx[slot0 + j]] = v;
+        ab_store(ab, (size_t)(rb * n + bidx[slot0 + j]), base + (u32)lo, (x == INF) ? 0u : nreal - (base + (u32)hi), nreal);
     }
 }
 
@@ -774,7 +759,7 @@ __global__ __launch_bounds__(BK_NT) void bucket_search_kernel(i64 n, int NB, con
 // fold the pair image into the totals of the targets: block = 64 targets x 16 row slices
 // =====================================================================================================
 template <int J>
-__global__ __launch_bounds__(1024) void rank_accumulate2_kernel(const AB2 *__restrict__ ab, const u32 *__restrict__ nnan,
+__global__ __launch_bounds__(1024) void rank_accumulate2_kernel(AB2 ab, const u32 *__restrict__ nnan,
                                                                 i64 rows, i64 n, const i64 *__restrict__ targets,
                                                                 i64 tbegin, i64 m, u64 *__restrict__ out, int first) {
     __shared__ u64 red[16][64];
@@ -786,22 +771,23 @@ __global__ __launch_bounds__(1024) void rank_accumulate2_kernel(const AB2 *__res
     for (int j = 0; j < JMAX - 1; ++j) acc[j] = 0;
     if (q < m) {
         i64 r = y;
+        auto fold = [&](u32 w, u32 nn, i64 row) {
+            if (w == AB2_NAN) return;
+            const u32 B = w & ~AB2_TIE;
+            const u32 A = (w & AB2_TIE) ? ab.A[row * n + i] : (u32)n - nn - 1u - B;     // tied keys carry their A
+            band_counts_add<J>(A, B, nn, (u64)(n - 1), acc);
+        };
         for (; r + 16 * 7 < rows; r += 16 * 8) {
-            AB2 v[8];
-            u32 nn[8];
+            u32 w[8], nn[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                v[u] = ab[(r + 16 * u) * n + i];
+                w[u] = ab.B[(r + 16 * u) * n + i];
                 nn[u] = nnan[r + 16 * u];
             }
 #pragma unroll
-            for (int u = 0; u < 8; ++u)
-                if (v[u].B != AB2_NAN) band_counts_add<J>(v[u].A, v[u].B, nn[u], (u64)(n - 1), acc);
+            for (int u = 0; u < 8; ++u) fold(w[u], nn[u], r + 16 * u);
         }
-        for (; r < rows; r += 16) {
-            const AB2 v = ab[r * n + i];
-            if (v.B != AB2_NAN) band_counts_add<J>(v.A, v.B, nnan[r], (u64)(n - 1), acc);
-        }
+        for (; r < rows; r += 16) fold(ab.B[r * n + i], nnan[r], r);
     }
 #pragma unroll
     for (int j = 0; j < J - 1; ++j) {
@@ -881,7 +867,9 @@ int launch_mbd_rank_big(const double *Y, i64 T, i64 n, const i64 *targets, i64 t
     const BigPlan p = big_plan(T, n);
     if (!ws || ws_bytes < p.total) return fail(SD_ERR_WORKSPACE, "large-n rank workspace too small");
     char *w = (char *)(((size_t)ws + 255) / 256 * 256);
-    AB2 *ab = (AB2 *)(w + p.off_ab);
+    AB2 ab;                                                 // per batch: rpb * n words of B, then as many of A
+    ab.B = (u32 *)(w + p.off_ab);
+    ab.A = ab.B + (size_t)p.rpb * n;
     double *sorted = (double *)(w + p.off_sorted);
     double *bval = (double *)(w + p.off_bval);
     u32 *bidx = (u32 *)(w + p.off_bidx);
@@ -976,7 +964,7 @@ int launch_mbd_rank_big(const double *Y, i64 T, i64 n, const i64 *targets, i64 t
         SD_HIP(hipGetLastError());
         const int first = row0 == 0;
         dim3 grid((unsigned)((m + 63) / 64));
-        SD_DISPATCH_J(J, hipLaunchKernelGGL((rank_accumulate2_kernel<J_>), grid, dim3(1024), 0, s, (const AB2 *)ab,
+        SD_DISPATCH_J(J, hipLaunchKernelGGL((rank_accumulate2_kernel<J_>), grid, dim3(1024), 0, s, ab,
                                             nn_for_fold, rows, n, targets, tbegin, m, out, first));
         SD_HIP(hipGetLastError());
     }
