@@ -1040,3 +1040,27 @@ def test_config4_componentwise_band_full_size(eng, oracle):
     assert got[:16].mean() > 10 * max(1.0, got[16:].mean())     # the central curves are deep, the rest much less
     one = eng.multi_band_counts(P[:, :, :1].contiguous())
     assert (one >= got).all()                                    # fewer features: never fewer containing pairs
+
+
+def test_homogeneity_with_block_sampling_is_reproducible(oracle):
+    """The K-sampled callers of the homogeneity coefficients (curves and point clouds) consume the global numpy RNG like
+    the reference's estimators do: the same seed gives the same coefficient, every value is finite, and the caller's
+    frames stay untouched."""
+    from statdepth_amd.homogeneity import FunctionalHomogeneity, PointcloudHomogeneity
+    rng = np.random.default_rng(61)
+    F = pd.DataFrame(rng.normal(size=(12, 10)).cumsum(axis=0), columns=[f"F{i}" for i in range(10)])
+    G = pd.DataFrame(rng.normal(size=(12, 8)).cumsum(axis=0) + 0.3, columns=[f"G{i}" for i in range(8)])
+    Fc, Gc = F.copy(), G.copy()
+    vals = []
+    for _ in range(2):
+        np.random.seed(314)
+        vals.append(float(np.asarray(FunctionalHomogeneity([F], [G], method="p3", K=2, relax=True, quiet=True).homogeneity()).ravel()[0]))
+    assert vals[0] == vals[1] and np.isfinite(vals[0])
+    assert F.equals(Fc) and G.equals(Gc)
+    P = pd.DataFrame(rng.normal(size=(14, 2)))
+    Q = pd.DataFrame(rng.normal(size=(14, 2)) + 0.2)
+    pv = []
+    for _ in range(2):
+        np.random.seed(2718)
+        pv.append(float(PointcloudHomogeneity(P, Q, method="p3", K=2).homogeneity()))
+    assert pv[0] == pv[1] and np.isfinite(pv[0])
