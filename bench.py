@@ -160,6 +160,8 @@ def extras_single_gpu(torch, dev, stream, lib, check, ALGOS, oracle, reps=10):
                                                               oc.data_ptr(), stream.cuda_stream)), 3, 1, stream, torch)
     tg = np.arange(0, 500, 31)
     assert (oc.cpu().numpy()[tg] == oracle.simplex_sampled(C, tg, relax=True, samples=256, seed=1236)).all(), "simplex d=8"
+    out["simplex_sampled_d8"] = {"workload": "500 curves x 50 timepoints x 8 features, 256 subsets per target (config 4 shape)",
+                                 "ms": ms, "simplex_tests_per_s": 500 * 256 * 50 / (ms * 1e-3), "checked_targets": len(tg)}
     # config 4 in its componentwise-band form ('r2_enum'): exact, every target
     n4, T4, d4 = 5000, 500, 8
     P4 = walks(torch, T4, n4 * d4, 1236, dev).view(T4, n4, d4).permute(1, 0, 2).contiguous()
@@ -177,8 +179,6 @@ def extras_single_gpu(torch, dev, stream, lib, check, ALGOS, oracle, reps=10):
                                          "(r2_enum), exact pair counts, all targets", "ms": ms,
                                          "curve_pairs_per_s": float(n4) * (n4 - 1) / (ms * 1e-3), "checked_targets": len(tg)}
     del P4, ws4
-    out["simplex_sampled_d8"] = {"workload": "500 curves x 50 timepoints x 8 features, 256 subsets per target (config 4 shape)",
-                                 "ms": ms, "simplex_tests_per_s": 500 * 256 * 50 / (ms * 1e-3), "checked_targets": len(tg)}
     return out
 
 
