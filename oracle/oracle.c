@@ -590,7 +590,7 @@ static void sample_subset(u64 seed, u64 tg, u64 sample, int k, long no, long *id
     u64 ctr = 0;
     for (int p = 0; p < k;) {
         u64 r = mix64(key + ctr++);
-        long c = (long)(r % (u64)no);
+        long c = (long)(((unsigned __int128)r * (unsigned __int128)(u64)no) >> 64);   /* floor(r * no / 2^64) */
         int dup = 0;
         for (int l = 0; l < p; ++l) dup |= (idx[l] == c);
         if (!dup) idx[p++] = c;

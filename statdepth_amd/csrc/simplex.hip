@@ -149,14 +149,16 @@ __device__ __host__ static inline u64 mix64(u64 z) {
     return z ^ (z >> 31);
 }
 
-// draw k distinct indices in [0,no) for (seed, tg, sample): rejection on duplicates,
+// draw k distinct indices in [0,no) for (seed, tg, sample): index = floor(r * no / 2^64), rejection on duplicates,
 // result sorted ascending.  Restated identically in oracle.c (oracle_sample_subset).
 __device__ static void sample_subset(u64 seed, u64 tg, u64 sample, int k, i64 no, i64 *idx) {
     u64 key = mix64(seed ^ mix64(tg * 0xD1342543DE82EF95ull + sample));
     u64 ctr = 0;
     for (int p = 0; p < k;) {
         u64 r = mix64(key + ctr++);
-        i64 c = (i64)(r % (u64)no);
+        // index in [0, no) as the high half of r * no (a 64 x 64 -> 128 bit product: a handful of instructions; the 64-bit
+        // modulo it replaces was ~480 of the 715 lane-instructions of a sampled 4-point test, profiles/r02_issue_roofline.json)
+        i64 c = (i64)__umul64hi(r, (u64)no);
         bool dup = false;
         for (int l = 0; l < p; ++l) dup |= (idx[l] == c);
         if (!dup) idx[p++] = c;
