@@ -5,7 +5,9 @@ import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from statdepth_amd import engine
+from statdepth_amd import engine, _native
+if os.environ.get("SD_LIB"):                     # experiments: another build of the library (this tool only)
+    _native.LIB_PATH = os.path.abspath(os.environ["SD_LIB"])
 what = sys.argv[1] if len(sys.argv) > 1 else "simplex8"
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 rng = np.random.default_rng(1236)
