@@ -494,7 +494,10 @@ __global__ __launch_bounds__(BK_NT) void bucket_packed_kernel(i64 n, int NB, con
 // are < / <= itself: B = (keys in earlier value buckets) + base + less, A = n_real - (... + base + le).  Ties are exact.
 // A value bucket whose keys are all equal is closed-form; one with a fine bucket above BR_CAP keys (heavy ties that
 // are not all equal, an infinity stretching the range) is flagged for bucket_search_kernel like before.
-constexpr int BR_NT = 512, BR_E = 16, BR_LNB = 12, BR_NBF = 1 << BR_LNB, BR_CAP = 63, BR_TRYB = 4, BR_U2 = 3, BR_PAD = 8;
+#ifndef SD_BR_U2
+#define SD_BR_U2 3
+#endif
+constexpr int BR_NT = 512, BR_E = 16, BR_LNB = 12, BR_NBF = 1 << BR_LNB, BR_CAP = 63, BR_TRYB = 4, BR_U2 = SD_BR_U2, BR_PAD = 8;
 static_assert(((BR_CAP + 1) & BR_CAP) == 0, "the crowding test reads the counters' bits");
 constexpr int BR_NW = BR_NT / 64;
 static_assert(BR_NT * BR_E == BK_C, "one thread slot per key of a full value bucket");
