@@ -213,3 +213,28 @@ def test_plot_helpers_build_figures():
         assert len(pres.plot_depths(invert_colors=True, return_plot=True).data) == 1
     with pytest.raises(ValueError, match="Dimensionality"):
         _PointwiseDepth(df=pc.iloc[:, :1], depths=pd.Series(index=pc.index, data=rng.random(12))).plot_depths(return_plot=True)
+
+
+def test_bench_contract_and_committed_evidence():
+    """bench.py's helpers without a GPU: the PMC traffic it quotes comes from a committed profile of the same workload and
+    is labelled with its file, and the round's recorded bench line carries the objects the measurement contract names."""
+    import importlib.util
+    import json
+    spec = importlib.util.spec_from_file_location("bench_module", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    traffic, source = bench.pmc_traffic(["rank_bucket_kernel", "rank_finalize"], 10000, 1000, 2)
+    assert source and source.startswith("profiles/") and os.path.exists(os.path.join(ROOT, source))
+    assert 0.5 * 160.08e6 < traffic < 1.5 * 160.08e6
+    assert bench.pmc_traffic(["rank_bucket_kernel"], 9999, 1000, 2) == (None, None)      # another workload: no quote
+    lines = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if "bench_line" in f and f.endswith(".json"))
+    assert lines
+    with open(os.path.join(ROOT, "profiles", lines[-1])) as f:
+        line = json.load(f)
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert key in line, key
+    assert line["dtype"] == "f64" and line["vs_baseline"] is None and "workload" in line["config"]
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert key in line["roofline"], key
+    assert abs(line["roofline"]["frac"] - line["roofline"]["achieved"] / line["roofline"]["peak"]) < 1e-9
