@@ -51,6 +51,20 @@ def pmc_traffic(kernels, n, T, J):
     return None, None
 
 
+def profiled_kernel_us(kernel, n, T, J):
+    """Average duration (us) of `kernel` in the newest committed rocprofv3 --stats summary of this workload
+    (profiles/*bench_kernel_stats.csv), with its file name; (None, None) for any other workload."""
+    if (n, T, J) != (10000, 1000, 2):
+        return None, None
+    import csv
+    for path in reversed(sorted(glob.glob(os.path.join(ROOT, "profiles", "*bench_kernel_stats.csv")))):
+        with open(path) as f:
+            for row in csv.DictReader(f):
+                if kernel in row.get("Name", ""):
+                    return float(row["AverageNs"]) / 1e3, os.path.relpath(path, ROOT)
+    return None, None
+
+
 def timed(fn, steps, warmup, stream, torch, barrier=None):
     """(wall seconds, device ms per step) of `steps` calls of fn(i) behind `warmup` untimed ones."""
     for i in range(warmup):
@@ -349,6 +363,7 @@ def main():
         bytes_alg = 8.0 * T * (n + n_loc) + 8.0 * n_loc * (J - 1)   # per GPU per call
         achieved = bytes_alg / (dev_ms * 1e-3)
         traffic, source = pmc_traffic(kerns, n, T, J) if N == 1 else (None, None)
+        kus, ksrc = profiled_kernel_us(kerns[0], n, T, J) if N == 1 else (None, None)
         mode = args.mode if args.mode != "auto" else ("time" if used == "rank" else "targets")
         line = {
             "metric": "curve-pairs/sec (MBD)", "value": value, "unit": "curve-pairs/s",
@@ -368,8 +383,12 @@ def main():
                          "hbm_rate": (traffic / (dev_ms * 1e-3) / 1e9) if traffic else None,
                          "kernel": kerns[0], "kernels_of_step": kerns,
                          "kernel_ms": dev_ms, "algorithmic_bytes": bytes_alg,
+                         "dominant_kernel_us_profiled": kus, "dominant_kernel_source": ksrc,
+                         "frac_dominant_kernel_profiled": (bytes_alg / (kus * 1e-6) / HBM_PEAK) if kus else None,
                          "note": "kernel_ms = device time of one whole step (all kernels of the step) by HIP events on the launch "
-                                 "stream; achieved = algorithmic_bytes / kernel_ms, a lower bound for the dominant kernel"},
+                                 "stream, measured in this run; achieved = algorithmic_bytes / kernel_ms, a lower bound for the "
+                                 "dominant kernel, whose own average duration (rocprofv3 --stats of the same command, committed "
+                                 "file named beside it) gives frac_dominant_kernel_profiled"},
             "checksum": result_sum,
         }
         if replay:
