@@ -24,8 +24,17 @@ constexpr int ST_WREG = 16;          // mask words kept in registers (T <= 1024)
 
 static inline i64 strict_words(i64 T) { return (T + 63) / 64; }
 
+// complement matching (see strict_match_insert_kernel): open-addressing table per target, slot = 64-bit key + two counters
+constexpr i64 ST_MATCH_MAXN = 65535;                     // the key carries a 16-bit curve id
+static inline i64 strict_table_slots(i64 n) {
+    i64 s = 64;
+    while (s < 2 * n) s <<= 1;
+    return s;
+}
+static inline bool strict_match_applies(i64 T, i64 n, int J) { return J == 2 && (T + 31) / 32 <= 32 && n <= ST_MATCH_MAXN; }
+
 static i64 strict_batch(i64 T, i64 n, i64 m) {
-    size_t per = (size_t)n * 2 * strict_words(T) * 8;
+    size_t per = (size_t)n * 2 * strict_words(T) * 8 + (size_t)strict_table_slots(n) * 16 + 20;
     i64 b = (i64)(((size_t)256 << 20) / (per ? per : 1));
     if (b < 1) b = 1;
     if (b > m) b = m;
@@ -36,7 +45,8 @@ static i64 strict_batch(i64 T, i64 n, i64 m) {
 size_t bd_strict_workspace_bytes(i64 T, i64 n, i64 m, int J) {
     (void)J;
     i64 b = strict_batch(T, n, m);
-    return align_up((size_t)b * n * 2 * strict_words(T) * 8, 256) + align_up((size_t)b * 4, 256) + 512;
+    return align_up((size_t)b * n * 2 * strict_words(T) * 8, 256) + align_up((size_t)b * 4, 256) +
+           align_up((size_t)b * (strict_table_slots(n) * 16 + 16), 256) + 1024;
 }
 
 // masks[b][i][0..W) = UN, masks[b][i][W..2W) = DN
@@ -196,7 +206,7 @@ __global__ __launch_bounds__(ST_THREADS) void strict_masks2_kernel(
 // grid = (a tiles, b chunks, batch)
 __global__ __launch_bounds__(ST_THREADS) void strict_pairs2_kernel(
     const u32 *__restrict__ m32, i64 T, i64 n, const i64 *__restrict__ targets, i64 q0,
-    const u32 *__restrict__ xnan, u64 *__restrict__ out, int jcols) {
+    const u32 *__restrict__ xnan, const u32 *__restrict__ dirty, u64 *__restrict__ out, int jcols) {
     __shared__ u64 scratch[ST_THREADS / 64];
     __shared__ u32 orparts[ST_THREADS / 64][2][ST_SUB];   // per wave: OR of its quarter of partner j's UN / DN words
     __shared__ __attribute__((aligned(16))) u32 cm[ST_SUB][2 * ST_W32 + 4];   // partner j: UN words 0..31, DN words 0..31 (zero
@@ -205,6 +215,7 @@ __global__ __launch_bounds__(ST_THREADS) void strict_pairs2_kernel(
     const i64 b = blockIdx.z;
     const i64 q = q0 + b;
     if (xnan[b]) return;                       // NaN in the target: nothing is contained
+    if (dirty && dirty[b * 4] == 0) return;        // every curve is strictly above or below at every timepoint: counted by matching
     const i64 tg = targets ? targets[q] : q;
     const i64 a = (i64)blockIdx.x * ST_THREADS + threadIdx.x;
     const i64 b0 = (i64)blockIdx.y * ST_BCHUNK;
@@ -303,6 +314,123 @@ __global__ __launch_bounds__(ST_THREADS) void strict_pairs2_kernel(
     if (threadIdx.x == 0 && tot) atomicAdd(&out[q * jcols], tot);
 }
 
+// ---------------------------------------------------------------------------------------------------
+// J = 2 by complement matching: O(n T) per target instead of O(n^2 T).
+// Call a curve CLEAN for a target when at every timepoint it is strictly above or strictly below it (no tie, no
+// NaN): DN = ~UN.  A pair of clean curves is contained at every timepoint iff at every timepoint exactly one of
+// them is above, i.e. iff UN_b == ~UN_a as T-bit masks: an EQUALITY, so the pairs can be counted by grouping
+// instead of testing.  Canonical form of a mask: itself (side 0) or its complement (side 1), whichever has the
+// smaller first word; complementary masks share their canonical form and sit on opposite sides, so
+//     clean-clean contained pairs = sum over distinct canonical masks of  count(side 0) * count(side 1).
+// The groups are formed in an open-addressing table per target (global memory, linear probing): a slot's key is
+// 48 hash bits of the canonical mask + the id of the first curve that claimed it (one 64-bit CAS, no lock, nothing
+// to wait for); a curve that meets a key with its hash compares its full canonical mask with that first curve's
+// before joining, so hash collisions cost a probe and never a wrong count.
+// When a target has any curve that is not clean (ties, NaN) the whole target goes to strict_pairs2_kernel instead
+// (meta[b][0] = number of such curves > 0); continuous data has none.
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ u64 strict_mix(u64 h, u32 w) {
+    h = (h ^ w) * 0xff51afd7ed558ccdull;
+    return h ^ (h >> 29);
+}
+
+// grid = (ceil(n / 256), nb)
+__global__ __launch_bounds__(ST_THREADS) void strict_match_insert_kernel(
+    const u32 *__restrict__ m32, i64 T, i64 n, const i64 *__restrict__ targets, i64 q0, const u32 *__restrict__ xnan,
+    u32 *__restrict__ meta, unsigned long long *__restrict__ keys, u32 *__restrict__ cnt, i64 slots) {
+    const i64 b = blockIdx.y;
+    if (xnan[b]) return;
+    const i64 tg = targets ? targets[q0 + b] : q0 + b;
+    const i64 a = (i64)blockIdx.x * ST_THREADS + threadIdx.x;
+    if (a >= n || a == tg) return;
+    const int W32 = (int)((T + 31) / 32);
+    const u32 lastvalid = (T & 31) ? ((1u << (T & 31)) - 1u) : 0xFFFFFFFFu;
+    const u32 *mb = m32 + (size_t)b * 2 * W32 * n;
+    // nothing is kept per word: the curve's words are read (coalesced, L2-resident) once for the hash and again only
+    // when a key with its hash turns up
+    const u32 v0 = W32 == 1 ? lastvalid : 0xFFFFFFFFu;
+    const u32 u0 = mb[a];
+    const u32 side = u0 > (~u0 & v0) ? 1u : 0u;              // canonical form: complement when that makes the first word smaller
+    const u32 flip = side ? 0xFFFFFFFFu : 0u;
+    bool clean = true;
+    u64 h = 0x9E3779B97F4A7C15ull;
+    u32 any = 0;
+#pragma unroll 4
+    for (int w = 0; w < W32; ++w) {
+        const u32 v = w == W32 - 1 ? lastvalid : 0xFFFFFFFFu;
+        const u32 un = mb[(size_t)w * n + a];
+        const u32 dn = mb[(size_t)(W32 + w) * n + a];
+        clean &= (un ^ dn) == v;
+        const u32 cw = (un ^ flip) & v;
+        any |= cw;
+        h = strict_mix(h, cw);
+    }
+    // one atomic per wave, not per lane (with ties nearly every lane lands here); a target with any such curve goes to
+    // the pair kernel as a whole, so the wave's clean lanes have nothing left to do either
+    {
+        const u64 nd = __ballot(!clean);
+        if (nd) {
+            if ((int)(threadIdx.x & 63) == __ffsll((long long)nd) - 1) atomicAdd(&meta[b * 4], (u32)__popcll(nd));
+            return;
+        }
+    }
+    // the empty canonical mask -- curves below the target throughout (side 0) or above it throughout (side 1) -- is the
+    // one big group of banded data: counted per wave with two ballots instead of n atomics on one table slot
+    {
+        const u64 z0 = __ballot(any == 0 && side == 0), z1 = __ballot(any == 0 && side == 1);
+        if (any == 0) {
+            const int lane = threadIdx.x & 63;
+            if (z0 && lane == __ffsll((long long)z0) - 1) atomicAdd(&meta[b * 4 + 1], (u32)__popcll(z0));
+            if (z1 && lane == __ffsll((long long)z1) - 1) atomicAdd(&meta[b * 4 + 2], (u32)__popcll(z1));
+            return;
+        }
+    }
+    h ^= h >> 32;
+    h *= 0xc4ceb9fe1a85ec53ull;
+    h ^= h >> 33;
+    const u64 tag = (h >> 16) | ((u64)1 << 47);               // 48 bits, never zero
+    const unsigned long long mine = (tag << 16) | (u64)a;
+    unsigned long long *kb = keys + (size_t)b * slots;
+    u32 *cb = cnt + (size_t)b * slots * 2;
+    i64 slot = (i64)(h & (u64)(slots - 1));
+    for (i64 probe = 0; probe < slots; ++probe) {             // the table has >= 2n slots: always ends early
+        unsigned long long cur = __hip_atomic_load(&kb[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (cur == 0) {
+            cur = atomicCAS(&kb[slot], 0ull, mine);
+            if (cur == 0) break;
+        }
+        if ((cur >> 16) == tag) {
+            // the first claimant's canonical mask against this curve's, word by word
+            const i64 rep = (i64)(cur & 0xFFFF);
+            const u32 r0 = mb[rep];
+            const u32 rflip = r0 > (~r0 & v0) ? 0xFFFFFFFFu : 0u;
+            bool same = true;
+#pragma unroll 1
+            for (int w = 0; w < W32 && same; ++w) {
+                const u32 v = w == W32 - 1 ? lastvalid : 0xFFFFFFFFu;
+                same = ((mb[(size_t)w * n + a] ^ flip) & v) == ((mb[(size_t)w * n + rep] ^ rflip) & v);
+            }
+            if (same) break;
+        }
+        slot = (slot + 1) & (slots - 1);
+    }
+    atomicAdd(&cb[slot * 2 + side], 1u);
+}
+
+// grid = nb: contained pairs of a target whose curves are all clean
+__global__ __launch_bounds__(ST_THREADS) void strict_match_total_kernel(
+    const u32 *__restrict__ cnt, i64 slots, i64 q0, const u32 *__restrict__ xnan, const u32 *__restrict__ meta,
+    u64 *__restrict__ out, int jcols) {
+    __shared__ u64 scratch[ST_THREADS / 64];
+    const i64 b = blockIdx.x;
+    if (xnan[b] || meta[b * 4] != 0) return;
+    const u32 *cb = cnt + (size_t)b * slots * 2;
+    u64 acc = threadIdx.x == 0 ? (u64)meta[b * 4 + 1] * (u64)meta[b * 4 + 2] : 0;
+    for (i64 i = threadIdx.x; i < slots; i += ST_THREADS) acc += (u64)cb[i * 2] * (u64)cb[i * 2 + 1];
+    const u64 tot = block_sum(acc, scratch);
+    if (threadIdx.x == 0) out[(q0 + b) * jcols] = tot;
+}
+
 // J = 3 / 4: one thread per (J-1)-prefix, loop over the last member.
 template <int J>
 __global__ __launch_bounds__(ST_THREADS) void strict_subsets_kernel(
@@ -353,7 +481,14 @@ int launch_bd_strict(const double *Y, i64 T, i64 n, const i64 *targets, i64 m, i
     Carver cv(ws, ws_bytes);
     u64 *masks = (u64 *)cv.take((size_t)B * n * 2 * W * 8);
     u32 *xnan = (u32 *)cv.take((size_t)B * 4);
-    if (!masks || !xnan) return fail(SD_ERR_WORKSPACE, "strict-depth workspace too small");
+    const i64 slots = strict_table_slots(n);
+    // cross-check builds, SD_STRICT_NOMATCH = 1: every target through the pair kernel
+    const bool match = strict_match_applies(T, n, J) && xswitch("SD_STRICT_V1") != 1 && xswitch("SD_STRICT_NOMATCH") != 1;
+    unsigned char *tab = (unsigned char *)cv.take((size_t)B * (slots * 16 + 16));  // keys | counters | per target {dirty, below, above, -}
+    if (!masks || !xnan || !tab) return fail(SD_ERR_WORKSPACE, "strict-depth workspace too small");
+    unsigned long long *keys = (unsigned long long *)tab;
+    u32 *cnt = (u32 *)(tab + (size_t)B * slots * 8);
+    u32 *dirty = (u32 *)(tab + (size_t)B * slots * 16);
     int jcols = J - 1;
     SD_HIP(hipMemsetAsync(out, 0, sizeof(u64) * m * jcols, s));
     if (J >= 3) {
@@ -372,8 +507,15 @@ int launch_bd_strict(const double *Y, i64 T, i64 n, const i64 *targets, i64 m, i
             // second generation: 32-bit words, word-major image (fits the same workspace: 2 W32 n u32 <= 2 W n u64)
             dim3 g1b((unsigned)((n + ST_THREADS - 1) / ST_THREADS), (unsigned)W32, (unsigned)((nb + ST_TG - 1) / ST_TG));
             hipLaunchKernelGGL(strict_masks2_kernel, g1b, dim3(ST_THREADS), 0, s, Y, T, n, targets, q0, nb, (u32 *)masks, xnan);
+            if (match) {
+                SD_HIP(hipMemsetAsync(tab, 0, (size_t)B * (slots * 16 + 16), s));
+                hipLaunchKernelGGL(strict_match_insert_kernel, g1, dim3(ST_THREADS), 0, s, (const u32 *)masks, T, n, targets, q0,
+                                   xnan, dirty, keys, cnt, slots);
+                hipLaunchKernelGGL(strict_match_total_kernel, dim3((unsigned)nb), dim3(ST_THREADS), 0, s, (const u32 *)cnt, slots,
+                                   q0, xnan, (const u32 *)dirty, out, jcols);
+            }
             hipLaunchKernelGGL(strict_pairs2_kernel, g2, dim3(ST_THREADS), 0, s, (const u32 *)masks, T, n, targets, q0, xnan,
-                               out, jcols);
+                               match ? (const u32 *)dirty : (const u32 *)nullptr, out, jcols);
             SD_HIP(hipGetLastError());
             continue;
         }

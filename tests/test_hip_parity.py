@@ -407,6 +407,45 @@ def test_strict_vs_oracle(eng, oracle, shape):
     assert (eng.bd_strict_counts(Xn)[:, 0] == oracle.bd_strict_counts(Xn)).all()
 
 
+@pytest.mark.parametrize("shape", [(5, 6), (31, 70), (32, 600), (33, 257), (64, 40), (100, 1300), (999, 300), (1000, 700),
+                                   (1024, 130)])
+def test_strict_complement_matching_vs_oracle(eng, oracle, xcheck, shape):
+    """Continuous data: every curve is strictly above or below the target at every timepoint, so the J = 2 count comes
+    from grouping complementary masks (strict_match_*_kernel) instead of the pair walk.  Banded curves (many equal
+    masks: whole groups above / below), crossing curves (unique masks), one exact mirror pair, and a duplicated curve
+    (its two copies are the only targets that fall back to the pair kernel)."""
+    rng = np.random.default_rng(shape[0] * 7919 + shape[1])
+    T, n = shape
+    X = np.sort(rng.normal(size=n))[None, :] * 3.0 + rng.normal(size=(T, n)) * 0.3
+    X[:, 3] = 2.0 * X[:, 2].mean() - X[:, 2]          # mirror image of curve 2 about a constant
+    if n > 40:
+        X[:, n // 2] = X[:, 7]                        # exact duplicate: ties at every timepoint for these two targets
+    want = oracle.bd_strict_counts(X)
+    assert want.sum() > 0
+    got = eng.bd_strict_counts(X)[:, 0]
+    assert (got == want).all()
+    assert (eng.bd_strict_counts(np.asfortranarray(X))[:, 0] == want).all()
+    tg = rng.permutation(n)[: max(2, n // 3)]
+    assert (eng.bd_strict_counts(X, tg)[:, 0] == want[tg]).all()
+    with xcheck(SD_STRICT_NOMATCH=1):
+        assert (eng.bd_strict_counts(X)[:, 0] == want).all()
+
+
+def test_strict_complement_matching_random_walks_vs_pair_kernel(eng, xcheck):
+    """2 000 random walks x 1 000 timepoints (the size the strict timings are quoted on): matching path against the
+    pair kernel of the cross-check library, plus curves built to be exact complements of each other."""
+    rng = np.random.default_rng(12)
+    T, n = 1000, 2000
+    X = rng.normal(size=(T, n)).cumsum(axis=0)
+    X[:, 100:160] += 400.0                            # a group always above everything
+    X[:, 200:250] -= 400.0                            # and one always below
+    got = eng.bd_strict_counts(X)[:, 0]
+    with xcheck(SD_STRICT_NOMATCH=1):
+        want = eng.bd_strict_counts(X)[:, 0]
+    assert (got == want).all()
+    assert got.sum() > 0
+
+
 def test_strict_J3_J4_vs_literal_enumeration(eng, oracle):
     rng = np.random.default_rng(4)
     X = np.round(np.sort(rng.normal(size=12))[None, :] * 2 + rng.normal(size=(6, 12)) * 0.4, 1)

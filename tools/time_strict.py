@@ -1,18 +1,28 @@
 #!/usr/bin/env python3
-"""Device time of sd_bd_strict_counts (J=2) on n curves x T timepoints, all targets."""
-import os, sys
+"""Device time of sd_bd_strict_counts (J=2) on n curves x T timepoints, all targets.
+usage: time_strict.py [n] [T] [kind]   kind: walks (default) | banded | rounded"""
+import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from statdepth_amd import engine
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
 T = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
-X = np.random.default_rng(3).normal(size=(T, n)).cumsum(axis=0)
-engine.bd_strict_counts(X, None, 2)
+kind = sys.argv[3] if len(sys.argv) > 3 else "walks"
+rng = np.random.default_rng(3)
+if kind == "walks":
+    X = rng.normal(size=(T, n)).cumsum(axis=0)
+elif kind == "banded":
+    X = np.sort(rng.normal(size=n))[None, :] * 3.0 + rng.normal(size=(T, n)) * 0.3
+else:
+    X = np.round(np.sort(rng.normal(size=n))[None, :] * 3.0 + rng.normal(size=(T, n)) * 0.3, 1)
+Xd = torch.from_numpy(X).cuda()
+out = engine.bd_strict_counts(Xd, None, 2)
 torch.cuda.synchronize()
-import time
+reps = 3
 t = time.perf_counter()
-for _ in range(3):
-    engine.bd_strict_counts(X, None, 2)
+for _ in range(reps):
+    engine.bd_strict_counts(Xd, None, 2)
 torch.cuda.synchronize()
-print(f"n={n} T={T}: {(time.perf_counter() - t) / 3 * 1e3:.2f} ms per call")
+tot = int(out.sum().item()) if hasattr(out, "sum") else 0
+print(f"strict n={n} T={T} {kind}: {(time.perf_counter() - t) / reps * 1e3:.2f} ms per call, contained pairs {tot}")
