@@ -31,10 +31,10 @@ static inline i64 strict_table_slots(i64 n) {
     while (s < 2 * n) s <<= 1;
     return s;
 }
-static inline bool strict_match_applies(i64 T, i64 n, int J) { return J == 2 && (T + 31) / 32 <= 32 && n <= ST_MATCH_MAXN; }
+static inline bool strict_match_applies(i64 T, i64 n, int J) { return J == 2 && (T + 31) / 32 <= 65535 && n <= ST_MATCH_MAXN; }
 
 static i64 strict_batch(i64 T, i64 n, i64 m) {
-    size_t per = (size_t)n * 2 * strict_words(T) * 8 + (size_t)strict_table_slots(n) * 16 + 20;
+    size_t per = (size_t)n * 2 * strict_words(T) * 8 + (size_t)strict_table_slots(n) * 16 + 20 + (size_t)((n + 63) / 64) * 8;
     i64 b = (i64)(((size_t)256 << 20) / (per ? per : 1));
     if (b < 1) b = 1;
     if (b > m) b = m;
@@ -46,15 +46,17 @@ size_t bd_strict_workspace_bytes(i64 T, i64 n, i64 m, int J) {
     (void)J;
     i64 b = strict_batch(T, n, m);
     return align_up((size_t)b * n * 2 * strict_words(T) * 8, 256) + align_up((size_t)b * 4, 256) +
-           align_up((size_t)b * (strict_table_slots(n) * 16 + 16), 256) + 1024;
+           align_up((size_t)b * (strict_table_slots(n) * 16 + 16 + ((n + 63) / 64) * 8), 256) +
+           align_up((size_t)((T + 31) / 32) * 4, 256) + 1024;
 }
 
 // masks[b][i][0..W) = UN, masks[b][i][W..2W) = DN
 __global__ __launch_bounds__(ST_THREADS) void strict_masks_kernel(
     const double *__restrict__ Y, i64 T, i64 n, const i64 *__restrict__ targets, i64 q0,
-    u64 *__restrict__ masks, u32 *__restrict__ xnan) {
+    u64 *__restrict__ masks, u32 *__restrict__ xnan, const u32 *__restrict__ gate) {
     i64 i = (i64)blockIdx.x * ST_THREADS + threadIdx.x;
     i64 b = blockIdx.y;
+    if (gate && gate[b * 4] == 0) return;      // target already counted by complement matching
     i64 q = q0 + b;
     i64 tg = targets ? targets[q] : q;
     i64 W = (T + 63) / 64;
@@ -97,11 +99,12 @@ constexpr int ST_BCHUNK = 512;
 template <bool REG>
 __global__ __launch_bounds__(ST_THREADS) void strict_pairs_kernel(
     const u64 *__restrict__ masks, i64 T, i64 n, const i64 *__restrict__ targets, i64 q0,
-    const u32 *__restrict__ xnan, u64 *__restrict__ out, int jcols) {
+    const u32 *__restrict__ xnan, const u32 *__restrict__ gate, u64 *__restrict__ out, int jcols) {
     __shared__ u64 scratch[ST_THREADS / 64];
     i64 b = blockIdx.z;
     i64 q = q0 + b;
     if (xnan[b]) return;                       // NaN in the target: nothing is contained
+    if (gate && gate[b * 4] == 0) return;      // target already counted by complement matching
     i64 tg = targets ? targets[q] : q;
     i64 a = (i64)blockIdx.x * ST_THREADS + threadIdx.x;
     i64 b0 = (i64)blockIdx.y * ST_BCHUNK;
@@ -206,7 +209,8 @@ __global__ __launch_bounds__(ST_THREADS) void strict_masks2_kernel(
 // grid = (a tiles, b chunks, batch)
 __global__ __launch_bounds__(ST_THREADS) void strict_pairs2_kernel(
     const u32 *__restrict__ m32, i64 T, i64 n, const i64 *__restrict__ targets, i64 q0,
-    const u32 *__restrict__ xnan, const u32 *__restrict__ dirty, u64 *__restrict__ out, int jcols) {
+    const u32 *__restrict__ xnan, const u32 *__restrict__ dirty, const u64 *__restrict__ dbits, u64 *__restrict__ out,
+    int jcols) {
     __shared__ u64 scratch[ST_THREADS / 64];
     __shared__ u32 orparts[ST_THREADS / 64][2][ST_SUB];   // per wave: OR of its quarter of partner j's UN / DN words
     __shared__ __attribute__((aligned(16))) u32 cm[ST_SUB][2 * ST_W32 + 4];   // partner j: UN words 0..31, DN words 0..31 (zero
@@ -216,6 +220,8 @@ __global__ __launch_bounds__(ST_THREADS) void strict_pairs2_kernel(
     const i64 q = q0 + b;
     if (xnan[b]) return;                       // NaN in the target: nothing is contained
     if (dirty && dirty[b * 4] == 0) return;        // every curve is strictly above or below at every timepoint: counted by matching
+    // with matching on, the pairs of two clean curves are counted there; here only pairs with a dirty member remain
+    const u64 *db = dbits ? dbits + (size_t)b * ((n + 63) / 64) : nullptr;
     const i64 tg = targets ? targets[q] : q;
     const i64 a = (i64)blockIdx.x * ST_THREADS + threadIdx.x;
     const i64 b0 = (i64)blockIdx.y * ST_BCHUNK;
@@ -237,9 +243,13 @@ __global__ __launch_bounds__(ST_THREADS) void strict_pairs2_kernel(
 #pragma unroll
     for (int w = 0; w < ST_W32; ++w) { ora |= un[w]; ord_ |= dn[w]; }
     const bool u0a = ora == 0, d0a = ord_ == 0;
+    const bool dirty_a = !db || (alive && ((db[a >> 6] >> (a & 63)) & 1));
+    const bool tile_dirty = __syncthreads_or(dirty_a) != 0;     // block-uniform
     u64 good = 0;
     for (i64 s0 = b0; s0 < b1; s0 += ST_SUB) {
         const int len = (int)(b1 - s0 < ST_SUB ? b1 - s0 : ST_SUB);
+        const u64 dsub = db ? db[s0 >> 6] : ~0ull;              // dirty partners of this sub-chunk (s0 is a multiple of 64)
+        if (!tile_dirty && dsub == 0) continue;                 // clean tile x clean partners: nothing to count here
         __syncthreads();                                        // the previous sub-chunk has been read
         for (int e = threadIdx.x; e < ST_SUB * 2 * ST_W32; e += ST_THREADS) {
             const int w2 = e / ST_SUB, j = e % ST_SUB;          // consecutive threads: consecutive partners of one word
@@ -285,6 +295,7 @@ __global__ __launch_bounds__(ST_THREADS) void strict_pairs2_kernel(
         u64 real = len == ST_SUB ? ~0ull : (((u64)1 << len) - 1);
         if (tg >= s0 && tg < s0 + len) real &= ~((u64)1 << (int)(tg - s0));
         surv = alive ? (surv & real) : 0;
+        if (!dirty_a) surv &= dsub;
         const i64 jf = a + 1 - s0;
         surv = (jf <= 0) ? surv : (jf >= 64 ? 0 : (surv >> (int)jf) << (int)jf);
         if (W32 <= 4) {
@@ -334,45 +345,84 @@ __device__ __forceinline__ u64 strict_mix(u64 h, u32 w) {
     return h ^ (h >> 29);
 }
 
+// Timepoints at which all curves hold the same value (a common start, say) constrain no pair: cmask has their bits, and
+// the matching treats them as absent (they would otherwise make every curve "tie" and send every target to the pair
+// kernel).  grid = W32 blocks, one per mask word.
+__global__ __launch_bounds__(ST_THREADS) void strict_const_rows_kernel(const double *__restrict__ Y, i64 T, i64 n,
+                                                                      u32 *__restrict__ cmask) {
+    __shared__ int differs;
+    const i64 t0 = (i64)blockIdx.x * 32;
+    u32 word = 0;
+    for (int k = 0; k < 32 && t0 + k < T; ++k) {
+        if (threadIdx.x == 0) differs = 0;
+        __syncthreads();
+        const double *row = Y + (t0 + k) * n;
+        const double first = row[0];
+        for (i64 i0 = 0; i0 < n; i0 += ST_THREADS) {
+            const i64 i = i0 + threadIdx.x;
+            if (i < n && !(row[i] == first)) differs = 1;       // NaN differs from everything
+            __syncthreads();
+            const int d = differs;                               // block-uniform
+            __syncthreads();
+            if (d) break;
+        }
+        if (!differs) word |= 1u << k;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) cmask[blockIdx.x] = word;
+}
+
 // grid = (ceil(n / 256), nb)
 __global__ __launch_bounds__(ST_THREADS) void strict_match_insert_kernel(
     const u32 *__restrict__ m32, i64 T, i64 n, const i64 *__restrict__ targets, i64 q0, const u32 *__restrict__ xnan,
-    u32 *__restrict__ meta, unsigned long long *__restrict__ keys, u32 *__restrict__ cnt, i64 slots) {
+    const u32 *__restrict__ cmask, u32 *__restrict__ meta, u64 *__restrict__ dbits, unsigned long long *__restrict__ keys,
+    u32 *__restrict__ cnt, i64 slots) {
     const i64 b = blockIdx.y;
     if (xnan[b]) return;
     const i64 tg = targets ? targets[q0 + b] : q0 + b;
     const i64 a = (i64)blockIdx.x * ST_THREADS + threadIdx.x;
-    if (a >= n || a == tg) return;
+    if (a >= n) return;
     const int W32 = (int)((T + 31) / 32);
     const u32 lastvalid = (T & 31) ? ((1u << (T & 31)) - 1u) : 0xFFFFFFFFu;
     const u32 *mb = m32 + (size_t)b * 2 * W32 * n;
+    // the first timepoint that counts decides the side of the canonical form (wave-uniform scan of cmask)
+    int wf = 0;
+    u32 vf = 0;
+    for (; wf < W32; ++wf) {
+        vf = (wf == W32 - 1 ? lastvalid : 0xFFFFFFFFu) & ~cmask[wf];
+        if (vf) break;
+    }
     // nothing is kept per word: the curve's words are read (coalesced, L2-resident) once for the hash and again only
     // when a key with its hash turns up
-    const u32 v0 = W32 == 1 ? lastvalid : 0xFFFFFFFFu;
-    const u32 u0 = mb[a];
-    const u32 side = u0 > (~u0 & v0) ? 1u : 0u;              // canonical form: complement when that makes the first word smaller
-    const u32 flip = side ? 0xFFFFFFFFu : 0u;
-    bool clean = true;
+    bool clean = vf != 0;                                    // every row constant: all curves tie everywhere, pair kernel
+    u32 side = 0, flip = 0;
+    if (vf) {
+        side = (mb[(size_t)wf * n + a] >> (__ffs((int)vf) - 1)) & 1u;   // canonical form: the mask or its complement,
+        flip = side ? 0xFFFFFFFFu : 0u;                                  // whichever is 0 at that timepoint
+    }
     u64 h = 0x9E3779B97F4A7C15ull;
     u32 any = 0;
 #pragma unroll 4
     for (int w = 0; w < W32; ++w) {
-        const u32 v = w == W32 - 1 ? lastvalid : 0xFFFFFFFFu;
+        const u32 v = (w == W32 - 1 ? lastvalid : 0xFFFFFFFFu) & ~cmask[w];
         const u32 un = mb[(size_t)w * n + a];
         const u32 dn = mb[(size_t)(W32 + w) * n + a];
-        clean &= (un ^ dn) == v;
+        clean &= ((un ^ dn) & v) == v && ((un & dn) == 0);    // above or below, not both (NaN), at every timepoint that counts
         const u32 cw = (un ^ flip) & v;
         any |= cw;
         h = strict_mix(h, cw);
     }
-    // one atomic per wave, not per lane (with ties nearly every lane lands here); a target with any such curve goes to
-    // the pair kernel as a whole, so the wave's clean lanes have nothing left to do either
+    // dirty curves: one bit each for the pair kernel (this wave owns word a / 64 of the target's bitmap), and their
+    // number -- one atomic per wave, with ties nearly every lane is dirty
     {
-        const u64 nd = __ballot(!clean);
-        if (nd) {
-            if ((int)(threadIdx.x & 63) == __ffsll((long long)nd) - 1) atomicAdd(&meta[b * 4], (u32)__popcll(nd));
-            return;
+        const bool isdirty = !clean && a != tg;
+        const u64 nd = __ballot(isdirty);
+        const int lane = threadIdx.x & 63;
+        if (lane == __ffsll((long long)__ballot(1)) - 1) {
+            dbits[(size_t)b * ((n + 63) / 64) + (a >> 6)] = nd;
+            if (nd) atomicAdd(&meta[b * 4], (u32)__popcll(nd));
         }
+        if (!clean || a == tg) return;
     }
     // the empty canonical mask -- curves below the target throughout (side 0) or above it throughout (side 1) -- is the
     // one big group of banded data: counted per wave with two ballots instead of n atomics on one table slot
@@ -402,12 +452,11 @@ __global__ __launch_bounds__(ST_THREADS) void strict_match_insert_kernel(
         if ((cur >> 16) == tag) {
             // the first claimant's canonical mask against this curve's, word by word
             const i64 rep = (i64)(cur & 0xFFFF);
-            const u32 r0 = mb[rep];
-            const u32 rflip = r0 > (~r0 & v0) ? 0xFFFFFFFFu : 0u;
+            const u32 rflip = ((mb[(size_t)wf * n + rep] >> (__ffs((int)vf) - 1)) & 1u) ? 0xFFFFFFFFu : 0u;
             bool same = true;
 #pragma unroll 1
             for (int w = 0; w < W32 && same; ++w) {
-                const u32 v = w == W32 - 1 ? lastvalid : 0xFFFFFFFFu;
+                const u32 v = (w == W32 - 1 ? lastvalid : 0xFFFFFFFFu) & ~cmask[w];
                 same = ((mb[(size_t)w * n + a] ^ flip) & v) == ((mb[(size_t)w * n + rep] ^ rflip) & v);
             }
             if (same) break;
@@ -417,13 +466,14 @@ __global__ __launch_bounds__(ST_THREADS) void strict_match_insert_kernel(
     atomicAdd(&cb[slot * 2 + side], 1u);
 }
 
-// grid = nb: contained pairs of a target whose curves are all clean
+// grid = nb: contained pairs of clean curves (the pair kernel adds those with a dirty member)
 __global__ __launch_bounds__(ST_THREADS) void strict_match_total_kernel(
     const u32 *__restrict__ cnt, i64 slots, i64 q0, const u32 *__restrict__ xnan, const u32 *__restrict__ meta,
-    u64 *__restrict__ out, int jcols) {
+    int whole_targets, u64 *__restrict__ out, int jcols) {
     __shared__ u64 scratch[ST_THREADS / 64];
     const i64 b = blockIdx.x;
-    if (xnan[b] || meta[b * 4] != 0) return;
+    if (xnan[b]) return;
+    if (whole_targets && meta[b * 4] != 0) return;   // the pair kernel that follows counts ALL pairs of such a target
     const u32 *cb = cnt + (size_t)b * slots * 2;
     u64 acc = threadIdx.x == 0 ? (u64)meta[b * 4 + 1] * (u64)meta[b * 4 + 2] : 0;
     for (i64 i = threadIdx.x; i < slots; i += ST_THREADS) acc += (u64)cb[i * 2] * (u64)cb[i * 2 + 1];
@@ -484,8 +534,12 @@ int launch_bd_strict(const double *Y, i64 T, i64 n, const i64 *targets, i64 m, i
     const i64 slots = strict_table_slots(n);
     // cross-check builds, SD_STRICT_NOMATCH = 1: every target through the pair kernel
     const bool match = strict_match_applies(T, n, J) && xswitch("SD_STRICT_V1") != 1 && xswitch("SD_STRICT_NOMATCH") != 1;
-    unsigned char *tab = (unsigned char *)cv.take((size_t)B * (slots * 16 + 16));  // keys | counters | per target {dirty, below, above, -}
-    if (!masks || !xnan || !tab) return fail(SD_ERR_WORKSPACE, "strict-depth workspace too small");
+    const i64 dwords = (n + 63) / 64;
+    // keys | counters | per target {dirty, below, above, -} | dirty bitmaps
+    unsigned char *tab = (unsigned char *)cv.take((size_t)B * (slots * 16 + 16 + dwords * 8));
+    u32 *cmask = (u32 *)cv.take((size_t)((T + 31) / 32) * 4);
+    if (!masks || !xnan || !tab || !cmask) return fail(SD_ERR_WORKSPACE, "strict-depth workspace too small");
+    u64 *dbits = (u64 *)(tab + (size_t)B * (slots * 16 + 16));
     unsigned long long *keys = (unsigned long long *)tab;
     u32 *cnt = (u32 *)(tab + (size_t)B * slots * 8);
     u32 *dirty = (u32 *)(tab + (size_t)B * slots * 16);
@@ -496,34 +550,44 @@ int launch_bd_strict(const double *Y, i64 T, i64 n, const i64 *targets, i64 m, i
         for (int k = 0; k < J - 1; ++k) threads *= (double)n;
         if (threads > 4.0e9) return fail(SD_ERR_UNSUPPORTED, "strict J=%d enumeration too large for n=%lld", J, (long long)n);
     }
+    if (match)
+        hipLaunchKernelGGL(strict_const_rows_kernel, dim3((unsigned)((T + 31) / 32)), dim3(ST_THREADS), 0, s, Y, T, n, cmask);
     for (i64 q0 = 0; q0 < m; q0 += B) {
         i64 nb = m - q0 < B ? m - q0 : B;
         SD_HIP(hipMemsetAsync(xnan, 0, (size_t)nb * 4, s));
         dim3 g1((unsigned)((n + ST_THREADS - 1) / ST_THREADS), (unsigned)nb);
         dim3 g2((unsigned)((n + ST_THREADS - 1) / ST_THREADS), (unsigned)((n + ST_BCHUNK - 1) / ST_BCHUNK), (unsigned)nb);
         const i64 W32 = (T + 31) / 32;
-        // cross-check builds, SD_STRICT_V1 = 1: the first-generation kernels (they serve T > 1024 and J > 2 anyway)
-        if (xswitch("SD_STRICT_V1") != 1 && J == 2 && W32 <= ST_W32) {
+        // cross-check builds, SD_STRICT_V1 = 1: the first-generation kernels only (they serve J > 2 anyway)
+        const bool gen2 = xswitch("SD_STRICT_V1") != 1 && J == 2 && W32 <= ST_W32;
+        const u32 *gate = nullptr;
+        if (gen2 || match) {
             // second generation: 32-bit words, word-major image (fits the same workspace: 2 W32 n u32 <= 2 W n u64)
             dim3 g1b((unsigned)((n + ST_THREADS - 1) / ST_THREADS), (unsigned)W32, (unsigned)((nb + ST_TG - 1) / ST_TG));
             hipLaunchKernelGGL(strict_masks2_kernel, g1b, dim3(ST_THREADS), 0, s, Y, T, n, targets, q0, nb, (u32 *)masks, xnan);
             if (match) {
-                SD_HIP(hipMemsetAsync(tab, 0, (size_t)B * (slots * 16 + 16), s));
+                SD_HIP(hipMemsetAsync(tab, 0, (size_t)B * (slots * 16 + 16 + dwords * 8), s));
                 hipLaunchKernelGGL(strict_match_insert_kernel, g1, dim3(ST_THREADS), 0, s, (const u32 *)masks, T, n, targets, q0,
-                                   xnan, dirty, keys, cnt, slots);
+                                   xnan, (const u32 *)cmask, dirty, dbits, keys, cnt, slots);
                 hipLaunchKernelGGL(strict_match_total_kernel, dim3((unsigned)nb), dim3(ST_THREADS), 0, s, (const u32 *)cnt, slots,
-                                   q0, xnan, (const u32 *)dirty, out, jcols);
+                                   q0, xnan, (const u32 *)dirty, gen2 ? 0 : 1, out, jcols);
+                gate = dirty;
             }
-            hipLaunchKernelGGL(strict_pairs2_kernel, g2, dim3(ST_THREADS), 0, s, (const u32 *)masks, T, n, targets, q0, xnan,
-                               match ? (const u32 *)dirty : (const u32 *)nullptr, out, jcols);
-            SD_HIP(hipGetLastError());
-            continue;
+            if (gen2) {
+                hipLaunchKernelGGL(strict_pairs2_kernel, g2, dim3(ST_THREADS), 0, s, (const u32 *)masks, T, n, targets, q0, xnan,
+                                   gate, gate ? (const u64 *)dbits : (const u64 *)nullptr, out, jcols);
+                SD_HIP(hipGetLastError());
+                continue;
+            }
+            // T > 1024: the pair kernel of the second generation keeps 2 x 32 words in registers and does not apply; the
+            // targets that matching could not take (ties, NaN) go through the first generation below, which rebuilds
+            // their masks in its own layout over the image just consumed (stream order)
         }
-        hipLaunchKernelGGL(strict_masks_kernel, g1, dim3(ST_THREADS), 0, s, Y, T, n, targets, q0, masks, xnan);
+        hipLaunchKernelGGL(strict_masks_kernel, g1, dim3(ST_THREADS), 0, s, Y, T, n, targets, q0, masks, xnan, gate);
         if (W <= ST_WREG)
-            hipLaunchKernelGGL((strict_pairs_kernel<true>), g2, dim3(ST_THREADS), 0, s, masks, T, n, targets, q0, xnan, out, jcols);
+            hipLaunchKernelGGL((strict_pairs_kernel<true>), g2, dim3(ST_THREADS), 0, s, masks, T, n, targets, q0, xnan, gate, out, jcols);
         else
-            hipLaunchKernelGGL((strict_pairs_kernel<false>), g2, dim3(ST_THREADS), 0, s, masks, T, n, targets, q0, xnan, out, jcols);
+            hipLaunchKernelGGL((strict_pairs_kernel<false>), g2, dim3(ST_THREADS), 0, s, masks, T, n, targets, q0, xnan, gate, out, jcols);
         if (J >= 3) {
             i64 flat = n * n;
             dim3 g3((unsigned)((flat + ST_THREADS - 1) / ST_THREADS), 1, (unsigned)nb);

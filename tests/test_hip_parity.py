@@ -408,12 +408,13 @@ def test_strict_vs_oracle(eng, oracle, shape):
 
 
 @pytest.mark.parametrize("shape", [(5, 6), (31, 70), (32, 600), (33, 257), (64, 40), (100, 1300), (999, 300), (1000, 700),
-                                   (1024, 130)])
+                                   (1024, 130), (1025, 45), (2100, 150)])
 def test_strict_complement_matching_vs_oracle(eng, oracle, xcheck, shape):
     """Continuous data: every curve is strictly above or below the target at every timepoint, so the J = 2 count comes
     from grouping complementary masks (strict_match_*_kernel) instead of the pair walk.  Banded curves (many equal
     masks: whole groups above / below), crossing curves (unique masks), one exact mirror pair, and a duplicated curve
-    (its two copies are the only targets that fall back to the pair kernel)."""
+    (its two copies are the only targets that fall back to the pair kernel).  Beyond 1 024 timepoints the fallback is
+    the first-generation pair kernel, gated per target."""
     rng = np.random.default_rng(shape[0] * 7919 + shape[1])
     T, n = shape
     X = np.sort(rng.normal(size=n))[None, :] * 3.0 + rng.normal(size=(T, n)) * 0.3
@@ -444,6 +445,37 @@ def test_strict_complement_matching_random_walks_vs_pair_kernel(eng, xcheck):
         want = eng.bd_strict_counts(X)[:, 0]
     assert (got == want).all()
     assert got.sum() > 0
+
+
+@pytest.mark.parametrize("shape", [(40, 300), (1000, 600), (1500, 200)])
+def test_strict_matching_with_common_values_and_sparse_ties(eng, oracle, xcheck, shape):
+    """The cases between 'all clean' and 'all ties': every curve shares its value at some timepoints (a common start:
+    those timepoints are dropped from the matching), a few curves touch other curves or hold NaN (only pairs with
+    such a curve go through the pair kernel; beyond 1 024 timepoints their targets do as a whole)."""
+    rng = np.random.default_rng(shape[0] + shape[1])
+    T, n = shape
+    X = np.sort(rng.normal(size=n))[None, :] * 3.0 + rng.normal(size=(T, n)) * 0.3
+    X[:, 3] = 2.0 * X[:, 2].mean() - X[:, 2]
+    X[0, :] = 0.0                                     # common start
+    X[T // 2, :] = 1.25                               # and a common value mid-way
+    Xa = X.copy()
+    want = oracle.bd_strict_counts(Xa)
+    assert want.sum() > 0
+    assert (eng.bd_strict_counts(Xa)[:, 0] == want).all()
+    # sparse ties: curve 5 touches curve 9 at three timepoints, curve 11 duplicates curve 12, curve 20 has NaN
+    Xb = X.copy()
+    Xb[[3, 7, T - 1], 5] = Xb[[3, 7, T - 1], 9]
+    Xb[:, 11] = Xb[:, 12]
+    Xb[T // 3, 20] = np.nan
+    wantb = oracle.bd_strict_counts(Xb)
+    gotb = eng.bd_strict_counts(Xb)[:, 0]
+    assert (gotb == wantb).all()
+    with xcheck(SD_STRICT_NOMATCH=1):
+        assert (eng.bd_strict_counts(Xb)[:, 0] == wantb).all()
+    # every row constant: every pair contains every target
+    Xc = np.tile(rng.normal(size=(T, 1)), (1, 9))
+    assert (eng.bd_strict_counts(Xc)[:, 0] == 28).all()
+    assert (oracle.bd_strict_counts(Xc) == 28).all()
 
 
 def test_strict_J3_J4_vs_literal_enumeration(eng, oracle):
