@@ -34,7 +34,7 @@ static inline i64 strict_table_slots(i64 n) {
 static inline bool strict_match_applies(i64 T, i64 n, int J) { return J == 2 && (T + 31) / 32 <= 65535 && n <= ST_MATCH_MAXN; }
 
 static i64 strict_batch(i64 T, i64 n, i64 m) {
-    size_t per = (size_t)n * 2 * strict_words(T) * 8 + (size_t)strict_table_slots(n) * 16 + 20 + (size_t)((n + 63) / 64) * 8;
+    size_t per = (size_t)n * 2 * strict_words(T) * 8 + (size_t)strict_table_slots(n) * 16 + 20 + (size_t)((n + 63) / 64) * 8 + (size_t)((T + 31) / 32) * 256;
     i64 b = (i64)(((size_t)256 << 20) / (per ? per : 1));
     if (b < 1) b = 1;
     if (b > m) b = m;
@@ -47,7 +47,7 @@ size_t bd_strict_workspace_bytes(i64 T, i64 n, i64 m, int J) {
     i64 b = strict_batch(T, n, m);
     return align_up((size_t)b * n * 2 * strict_words(T) * 8, 256) + align_up((size_t)b * 4, 256) +
            align_up((size_t)b * (strict_table_slots(n) * 16 + 16 + ((n + 63) / 64) * 8), 256) +
-           align_up((size_t)((T + 31) / 32) * 4, 256) + 1024;
+           align_up((size_t)((T + 31) / 32) * 4, 256) + align_up((size_t)b * ((T + 31) / 32) * 256, 256) + 1280;
 }
 
 // masks[b][i][0..W) = UN, masks[b][i][W..2W) = DN
@@ -168,15 +168,33 @@ constexpr int ST_W32 = 32;                  // mask words per kind kept in regis
 constexpr int ST_TG = 32;                   // targets per block of the mask kernel
 constexpr int ST_SUB = 64;
 
+// The batch's target curves, gathered curve-major and padded to whole words: Yt[b][t], t < Tp = 32 W32 (zero beyond T).
+// The mask kernel then fetches a target's 32 values of a word with a few wide scalar loads instead of 32 strided ones;
+// a NaN anywhere in the target is noted here.  grid = nb
+__global__ __launch_bounds__(ST_THREADS) void strict_gather_targets_kernel(
+    const double *__restrict__ Y, i64 T, i64 n, const i64 *__restrict__ targets, i64 q0, double *__restrict__ Yt,
+    u32 *__restrict__ xnan) {
+    const i64 b = blockIdx.x;
+    const i64 tg = targets ? targets[q0 + b] : q0 + b;
+    const i64 Tp = ((T + 31) / 32) * 32;
+    bool isn = false;
+    for (i64 t = threadIdx.x; t < Tp; t += ST_THREADS) {
+        const double v = t < T ? Y[t * n + tg] : 0.0;
+        isn |= v != v;
+        Yt[b * Tp + t] = v;
+    }
+    if (__syncthreads_or(isn) && threadIdx.x == 0) xnan[b] = 1;
+}
+
 // grid = (ceil(n / 256), W32, ceil(nb / ST_TG))
 __global__ __launch_bounds__(ST_THREADS) void strict_masks2_kernel(
-    const double *__restrict__ Y, i64 T, i64 n, const i64 *__restrict__ targets, i64 q0, i64 nb,
-    u32 *__restrict__ m32, u32 *__restrict__ xnan) {
+    const double *__restrict__ Y, const double *__restrict__ Yt, i64 T, i64 n, i64 nb, u32 *__restrict__ m32) {
     const i64 i = (i64)blockIdx.x * ST_THREADS + threadIdx.x;
     const int k = blockIdx.y;
     const int W32 = (int)((T + 31) / 32);
     const i64 t0 = (i64)k * 32;
     const int tl = (int)(T - t0 < 32 ? T - t0 : 32);
+    const u32 valid = tl == 32 ? 0xFFFFFFFFu : ((1u << tl) - 1u);
     double x[32];
     u32 nanbits = 0;
 #pragma unroll
@@ -186,23 +204,18 @@ __global__ __launch_bounds__(ST_THREADS) void strict_masks2_kernel(
     }
     const i64 bend = ((i64)blockIdx.z + 1) * ST_TG < nb ? ((i64)blockIdx.z + 1) * ST_TG : nb;
     for (i64 b = (i64)blockIdx.z * ST_TG; b < bend; ++b) {
-        const i64 tg = targets ? targets[q0 + b] : q0 + b;
+        const double *__restrict__ xq = Yt + (b * W32 + k) * 32;    // wave-uniform, contiguous: wide scalar loads
         u32 un = nanbits, dn = nanbits;
-        bool tnan = false;
 #pragma unroll
-        for (int t = 0; t < 32; ++t) {
-            if (t < tl) {                                   // block-uniform
-                const double xq = Y[(t0 + t) * n + tg];     // wave-uniform: scalar load
-                tnan |= xq != xq;
-                un |= (x[t] > xq) ? (1u << t) : 0u;
-                dn |= (x[t] < xq) ? (1u << t) : 0u;
-            }
+        for (int t = 0; t < 32; ++t) {                              // no branch in here: the loads issue together
+            const double q = xq[t];
+            un |= (x[t] > q) ? (1u << t) : 0u;
+            dn |= (x[t] < q) ? (1u << t) : 0u;
         }
         if (i < n) {
-            m32[((size_t)b * 2 * W32 + k) * n + i] = un;
-            m32[((size_t)b * 2 * W32 + W32 + k) * n + i] = dn;
+            m32[((size_t)b * 2 * W32 + k) * n + i] = un & valid;
+            m32[((size_t)b * 2 * W32 + W32 + k) * n + i] = dn & valid;
         }
-        if (tnan && blockIdx.x == 0 && threadIdx.x == 0) xnan[b] = 1;
     }
 }
 
@@ -538,7 +551,8 @@ int launch_bd_strict(const double *Y, i64 T, i64 n, const i64 *targets, i64 m, i
     // keys | counters | per target {dirty, below, above, -} | dirty bitmaps
     unsigned char *tab = (unsigned char *)cv.take((size_t)B * (slots * 16 + 16 + dwords * 8));
     u32 *cmask = (u32 *)cv.take((size_t)((T + 31) / 32) * 4);
-    if (!masks || !xnan || !tab || !cmask) return fail(SD_ERR_WORKSPACE, "strict-depth workspace too small");
+    double *Yt = (double *)cv.take((size_t)B * ((T + 31) / 32) * 256);
+    if (!masks || !xnan || !tab || !cmask || !Yt) return fail(SD_ERR_WORKSPACE, "strict-depth workspace too small");
     u64 *dbits = (u64 *)(tab + (size_t)B * (slots * 16 + 16));
     unsigned long long *keys = (unsigned long long *)tab;
     u32 *cnt = (u32 *)(tab + (size_t)B * slots * 8);
@@ -564,7 +578,9 @@ int launch_bd_strict(const double *Y, i64 T, i64 n, const i64 *targets, i64 m, i
         if (gen2 || match) {
             // second generation: 32-bit words, word-major image (fits the same workspace: 2 W32 n u32 <= 2 W n u64)
             dim3 g1b((unsigned)((n + ST_THREADS - 1) / ST_THREADS), (unsigned)W32, (unsigned)((nb + ST_TG - 1) / ST_TG));
-            hipLaunchKernelGGL(strict_masks2_kernel, g1b, dim3(ST_THREADS), 0, s, Y, T, n, targets, q0, nb, (u32 *)masks, xnan);
+            hipLaunchKernelGGL(strict_gather_targets_kernel, dim3((unsigned)nb), dim3(ST_THREADS), 0, s, Y, T, n, targets, q0, Yt,
+                               xnan);
+            hipLaunchKernelGGL(strict_masks2_kernel, g1b, dim3(ST_THREADS), 0, s, Y, (const double *)Yt, T, n, nb, (u32 *)masks);
             if (match) {
                 SD_HIP(hipMemsetAsync(tab, 0, (size_t)B * (slots * 16 + 16 + dwords * 8), s));
                 hipLaunchKernelGGL(strict_match_insert_kernel, g1, dim3(ST_THREADS), 0, s, (const u32 *)masks, T, n, targets, q0,
