@@ -35,7 +35,7 @@ static inline bool strict_match_applies(i64 T, i64 n, int J) { return J == 2 && 
 
 static i64 strict_batch(i64 T, i64 n, i64 m) {
     size_t per = (size_t)n * 2 * strict_words(T) * 8 + (size_t)strict_table_slots(n) * 16 + 20 + (size_t)((n + 63) / 64) * 8 + (size_t)((T + 31) / 32) * 256;
-    i64 b = (i64)(((size_t)256 << 20) / (per ? per : 1));
+    i64 b = (i64)(((size_t)2048 << 20) / (per ? per : 1));   // up to 2 GiB of masks and tables per batch
     if (b < 1) b = 1;
     if (b > m) b = m;
     if (b > 65535) b = 65535;
@@ -415,15 +415,25 @@ __global__ __launch_bounds__(ST_THREADS) void strict_match_insert_kernel(
     }
     u64 h = 0x9E3779B97F4A7C15ull;
     u32 any = 0;
-#pragma unroll 4
-    for (int w = 0; w < W32; ++w) {
-        const u32 v = (w == W32 - 1 ? lastvalid : 0xFFFFFFFFu) & ~cmask[w];
-        const u32 un = mb[(size_t)w * n + a];
-        const u32 dn = mb[(size_t)(W32 + w) * n + a];
-        clean &= ((un ^ dn) & v) == v && ((un & dn) == 0);    // above or below, not both (NaN), at every timepoint that counts
-        const u32 cw = (un ^ flip) & v;
-        any |= cw;
-        h = strict_mix(h, cw);
+    for (int w0 = 0; w0 < W32; w0 += 8) {
+        u32 un[8], dn[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {                         // sixteen loads in flight
+            const int w = w0 + j < W32 ? w0 + j : W32 - 1;
+            un[j] = mb[(size_t)w * n + a];
+            dn[j] = mb[(size_t)(W32 + w) * n + a];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int w = w0 + j;
+            if (w < W32) {
+                const u32 v = (w == W32 - 1 ? lastvalid : 0xFFFFFFFFu) & ~cmask[w];
+                clean &= ((un[j] ^ dn[j]) & v) == v && ((un[j] & dn[j]) == 0);   // above or below, not both (NaN), wherever it counts
+                const u32 cw = (un[j] ^ flip) & v;
+                any |= cw;
+                h = strict_mix(h, cw);
+            }
+        }
     }
     // dirty curves: one bit each for the pair kernel (this wave owns word a / 64 of the target's bitmap), and their
     // number -- one atomic per wave, with ties nearly every lane is dirty
@@ -479,7 +489,8 @@ __global__ __launch_bounds__(ST_THREADS) void strict_match_insert_kernel(
     atomicAdd(&cb[slot * 2 + side], 1u);
 }
 
-// grid = nb: contained pairs of clean curves (the pair kernel adds those with a dirty member)
+// grid = (nb, ceil(slots / ST_TOTAL_CHUNK)): contained pairs of clean curves (the pair kernel adds those with a dirty member)
+constexpr int ST_TOTAL_CHUNK = 4096;
 __global__ __launch_bounds__(ST_THREADS) void strict_match_total_kernel(
     const u32 *__restrict__ cnt, i64 slots, i64 q0, const u32 *__restrict__ xnan, const u32 *__restrict__ meta,
     int whole_targets, u64 *__restrict__ out, int jcols) {
@@ -487,11 +498,16 @@ __global__ __launch_bounds__(ST_THREADS) void strict_match_total_kernel(
     const i64 b = blockIdx.x;
     if (xnan[b]) return;
     if (whole_targets && meta[b * 4] != 0) return;   // the pair kernel that follows counts ALL pairs of such a target
-    const u32 *cb = cnt + (size_t)b * slots * 2;
-    u64 acc = threadIdx.x == 0 ? (u64)meta[b * 4 + 1] * (u64)meta[b * 4 + 2] : 0;
-    for (i64 i = threadIdx.x; i < slots; i += ST_THREADS) acc += (u64)cb[i * 2] * (u64)cb[i * 2 + 1];
+    const uint2 *cb = reinterpret_cast<const uint2 *>(cnt) + (size_t)b * slots;
+    const i64 i0 = (i64)blockIdx.y * ST_TOTAL_CHUNK;
+    const i64 i1 = i0 + ST_TOTAL_CHUNK < slots ? i0 + ST_TOTAL_CHUNK : slots;
+    u64 acc = (threadIdx.x == 0 && blockIdx.y == 0) ? (u64)meta[b * 4 + 1] * (u64)meta[b * 4 + 2] : 0;
+    for (i64 i = i0 + threadIdx.x; i < i1; i += ST_THREADS) {
+        const uint2 c = cb[i];
+        acc += (u64)c.x * (u64)c.y;
+    }
     const u64 tot = block_sum(acc, scratch);
-    if (threadIdx.x == 0) out[(q0 + b) * jcols] = tot;
+    if (threadIdx.x == 0 && tot) atomicAdd(&out[(q0 + b) * jcols], tot);
 }
 
 // J = 3 / 4: one thread per (J-1)-prefix, loop over the last member.
@@ -585,8 +601,9 @@ int launch_bd_strict(const double *Y, i64 T, i64 n, const i64 *targets, i64 m, i
                 SD_HIP(hipMemsetAsync(tab, 0, (size_t)B * (slots * 16 + 16 + dwords * 8), s));
                 hipLaunchKernelGGL(strict_match_insert_kernel, g1, dim3(ST_THREADS), 0, s, (const u32 *)masks, T, n, targets, q0,
                                    xnan, (const u32 *)cmask, dirty, dbits, keys, cnt, slots);
-                hipLaunchKernelGGL(strict_match_total_kernel, dim3((unsigned)nb), dim3(ST_THREADS), 0, s, (const u32 *)cnt, slots,
-                                   q0, xnan, (const u32 *)dirty, gen2 ? 0 : 1, out, jcols);
+                hipLaunchKernelGGL(strict_match_total_kernel,
+                                   dim3((unsigned)nb, (unsigned)((slots + ST_TOTAL_CHUNK - 1) / ST_TOTAL_CHUNK)), dim3(ST_THREADS), 0,
+                                   s, (const u32 *)cnt, slots, q0, xnan, (const u32 *)dirty, gen2 ? 0 : 1, out, jcols);
                 gate = dirty;
             }
             if (gen2) {
