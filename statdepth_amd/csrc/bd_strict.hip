@@ -34,7 +34,7 @@ static inline i64 strict_table_slots(i64 n) {
 static inline bool strict_match_applies(i64 T, i64 n, int J) { return J == 2 && (T + 31) / 32 <= 65535 && n <= ST_MATCH_MAXN; }
 
 static i64 strict_batch(i64 T, i64 n, i64 m) {
-    size_t per = (size_t)n * 2 * strict_words(T) * 8 + (size_t)strict_table_slots(n) * 16 + 20 + (size_t)((n + 63) / 64) * 8 + (size_t)((T + 31) / 32) * 256;
+    size_t per = (size_t)n * 2 * strict_words(T) * 8 + (size_t)strict_table_slots(n) * 16 + 20 + (size_t)((n + 63) / 64) * 8 + (size_t)((T + 31) / 32) * 256 + (size_t)n * 8;
     i64 b = (i64)(((size_t)2048 << 20) / (per ? per : 1));   // up to 2 GiB of masks and tables per batch
     if (b < 1) b = 1;
     if (b > m) b = m;
@@ -47,7 +47,8 @@ size_t bd_strict_workspace_bytes(i64 T, i64 n, i64 m, int J) {
     i64 b = strict_batch(T, n, m);
     return align_up((size_t)b * n * 2 * strict_words(T) * 8, 256) + align_up((size_t)b * 4, 256) +
            align_up((size_t)b * (strict_table_slots(n) * 16 + 16 + ((n + 63) / 64) * 8), 256) +
-           align_up((size_t)((T + 31) / 32) * 4, 256) + align_up((size_t)b * ((T + 31) / 32) * 256, 256) + 1280;
+           align_up((size_t)((T + 31) / 32) * 4, 256) + align_up((size_t)b * ((T + 31) / 32) * 256, 256) +
+           align_up((size_t)b * n * 8, 256) + 2048;
 }
 
 // masks[b][i][0..W) = UN, masks[b][i][W..2W) = DN
@@ -219,6 +220,87 @@ __global__ __launch_bounds__(ST_THREADS) void strict_masks2_kernel(
     }
 }
 
+// What the complement matching below needs per (target, curve), read off the masks once:
+//   HF[b][i] = payload (60 bits) << 4 | exact << 3 | side << 2 | canonical mask non-empty << 1 | clean
+// payload: the canonical mask itself when it has one non-zero word (exact = 1: word index << 32 | word), else 60 hash bits
+// (canonical form, side, clean: see the matching section; cmask marks the timepoints that do not count).
+// grid = (ceil(n / 256), nb); the words of a curve are n apart (word-major image): every load is coalesced.
+// (Folding this into the mask kernel was measured: carrying 8 or 16 targets' hashes in VGPRs across all words costs
+// the occupancy and the 32-target reuse of the curve values that strict_masks2_kernel lives on -- 30 and 47 ms instead
+// of 17.6 + 6 ms at 10 000 x 1 000.)
+__device__ __forceinline__ u64 strict_mix(u64 h, u32 w) {
+    h = (h ^ w) * 0xff51afd7ed558ccdull;
+    return h ^ (h >> 29);
+}
+
+struct StrictFirst {            // the first timepoint that counts: word and bit (wave-uniform)
+    int wf;
+    u32 vf;
+};
+__device__ __forceinline__ StrictFirst strict_first_counting(const u32 *__restrict__ cmask, int W32, u32 lastvalid) {
+    StrictFirst f{0, 0u};
+    for (; f.wf < W32; ++f.wf) {
+        f.vf = (f.wf == W32 - 1 ? lastvalid : 0xFFFFFFFFu) & ~cmask[f.wf];
+        if (f.vf) break;
+    }
+    return f;
+}
+
+__global__ __launch_bounds__(ST_THREADS) void strict_hash_kernel(const u32 *__restrict__ m32, i64 T, i64 n,
+                                                                const u32 *__restrict__ xnan, const u32 *__restrict__ cmask,
+                                                                u64 *__restrict__ HF) {
+    const i64 b = blockIdx.y;
+    if (xnan[b]) return;
+    const i64 a = (i64)blockIdx.x * ST_THREADS + threadIdx.x;
+    if (a >= n) return;
+    const int W32 = (int)((T + 31) / 32);
+    const u32 lastvalid = (T & 31) ? ((1u << (T & 31)) - 1u) : 0xFFFFFFFFu;
+    const u32 *mb = m32 + (size_t)b * 2 * W32 * n;
+    const StrictFirst fc = strict_first_counting(cmask, W32, lastvalid);
+    bool clean = fc.vf != 0;                                  // every row constant: nothing is clean (pair kernel)
+    u32 side = 0, flip = 0;
+    if (fc.vf) {
+        side = (mb[(size_t)fc.wf * n + a] >> (__ffs((int)fc.vf) - 1)) & 1u;
+        flip = side ? 0xFFFFFFFFu : 0u;
+    }
+    u64 h = 0x9E3779B97F4A7C15ull;
+    u32 one = 0, onek = 0, nz = 0;                            // the only non-zero canonical word, its index, how many there are
+    for (int w0 = 0; w0 < W32; w0 += 8) {
+        u32 un[8], dn[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {                         // sixteen loads in flight
+            const int w = w0 + j < W32 ? w0 + j : W32 - 1;
+            un[j] = mb[(size_t)w * n + a];
+            dn[j] = mb[(size_t)(W32 + w) * n + a];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int w = w0 + j;
+            if (w < W32) {
+                const u32 v = (w == W32 - 1 ? lastvalid : 0xFFFFFFFFu) & ~cmask[w];
+                clean &= ((un[j] ^ dn[j]) & v) == v && ((un[j] & dn[j]) == 0);   // above or below, not both (NaN), wherever it counts
+                const u32 cw = (un[j] ^ flip) & v;
+                if (cw) { one = cw; onek = (u32)w; ++nz; }
+                h = strict_mix(h, cw);
+            }
+        }
+    }
+    // a canonical mask with a single non-zero word is described EXACTLY by (index, word): equal payloads are equal
+    // masks and need no look at the masks (most groups of real data: curves that cross the target within one stretch
+    // of 32 timepoints and stay on one side otherwise)
+    const bool exact = nz <= 1;
+    u64 payload;
+    if (exact) {
+        payload = ((u64)onek << 32) | one;
+    } else {
+        h ^= h >> 32;
+        h *= 0xc4ceb9fe1a85ec53ull;
+        h ^= h >> 33;
+        payload = h >> 4;
+    }
+    HF[(size_t)b * n + a] = (payload << 4) | ((exact ? 1u : 0u) << 3) | (side << 2) | ((nz ? 1u : 0u) << 1) | (clean ? 1u : 0u);
+}
+
 // grid = (a tiles, b chunks, batch)
 __global__ __launch_bounds__(ST_THREADS) void strict_pairs2_kernel(
     const u32 *__restrict__ m32, i64 T, i64 n, const i64 *__restrict__ targets, i64 q0,
@@ -340,24 +422,19 @@ __global__ __launch_bounds__(ST_THREADS) void strict_pairs2_kernel(
 
 // ---------------------------------------------------------------------------------------------------
 // J = 2 by complement matching: O(n T) per target instead of O(n^2 T).
-// Call a curve CLEAN for a target when at every timepoint it is strictly above or strictly below it (no tie, no
-// NaN): DN = ~UN.  A pair of clean curves is contained at every timepoint iff at every timepoint exactly one of
-// them is above, i.e. iff UN_b == ~UN_a as T-bit masks: an EQUALITY, so the pairs can be counted by grouping
-// instead of testing.  Canonical form of a mask: itself (side 0) or its complement (side 1), whichever has the
-// smaller first word; complementary masks share their canonical form and sit on opposite sides, so
+// Call a curve CLEAN for a target when at every timepoint that counts it is strictly above or strictly below it (no
+// tie, no NaN): DN = ~UN.  A pair of clean curves is contained at every timepoint iff at every timepoint exactly one
+// of them is above, i.e. iff UN_b == ~UN_a as T-bit masks: an EQUALITY, so the pairs can be counted by grouping
+// instead of testing.  Canonical form of a mask: itself (side 0) or its complement (side 1), whichever is 0 at the
+// first timepoint that counts; complementary masks share their canonical form and sit on opposite sides, so
 //     clean-clean contained pairs = sum over distinct canonical masks of  count(side 0) * count(side 1).
-// The groups are formed in an open-addressing table per target (global memory, linear probing): a slot's key is
-// 48 hash bits of the canonical mask + the id of the first curve that claimed it (one 64-bit CAS, no lock, nothing
-// to wait for); a curve that meets a key with its hash compares its full canonical mask with that first curve's
-// before joining, so hash collisions cost a probe and never a wrong count.
-// When a target has any curve that is not clean (ties, NaN) the whole target goes to strict_pairs2_kernel instead
-// (meta[b][0] = number of such curves > 0); continuous data has none.
+// The empty canonical mask (curves below / above the target throughout) is counted directly; the others are grouped
+// in an open-addressing table per target keyed by a digest of the canonical mask (strict_hash_kernel).  A slot holds hash bits + the id of the first curve that claimed it (one CAS, no lock,
+// nothing to wait for); a curve that meets a key with its hash compares its full canonical mask with that first
+// curve's before joining, so hash collisions cost a probe and never a wrong count.
+// Curves that are not clean (ties, NaN) are DIRTY: pairs with a dirty member are counted by strict_pairs2_kernel,
+// which skips everything else (dirty bitmap per target); continuous data has none and the pair kernel exits at once.
 // ---------------------------------------------------------------------------------------------------
-__device__ __forceinline__ u64 strict_mix(u64 h, u32 w) {
-    h = (h ^ w) * 0xff51afd7ed558ccdull;
-    return h ^ (h >> 29);
-}
-
 // Timepoints at which all curves hold the same value (a common start, say) constrain no pair: cmask has their bits, and
 // the matching treats them as absent (they would otherwise make every curve "tie" and send every target to the pair
 // kernel).  grid = W32 blocks, one per mask word.
@@ -385,11 +462,130 @@ __global__ __launch_bounds__(ST_THREADS) void strict_const_rows_kernel(const dou
     if (threadIdx.x == 0) cmask[blockIdx.x] = word;
 }
 
+// do curves a and rep have the same canonical mask for this target?  Equal HF words (payload, exact flag; sides apart)
+// are required; exact payloads settle it, hashed ones (masks spread over several words) are confirmed on the masks.
+__device__ __forceinline__ bool strict_same_canonical(const u32 *__restrict__ mb, i64 n, int W32, u32 lastvalid,
+                                                      const u32 *__restrict__ cmask, i64 a, u64 hfa, i64 rep, u64 hfr) {
+    if ((hfa >> 3) != (hfr >> 3)) return false;
+    if (hfa & 8) return true;
+    const u32 flip = (hfa & 4) ? 0xFFFFFFFFu : 0u, rflip = (hfr & 4) ? 0xFFFFFFFFu : 0u;
+    u32 diff = 0;
+    for (int w0 = 0; w0 < W32; w0 += 8) {
+        u32 ma[8], mr[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {                         // sixteen loads in flight
+            const int w = w0 + j < W32 ? w0 + j : W32 - 1;
+            ma[j] = mb[(size_t)w * n + a];
+            mr[j] = mb[(size_t)w * n + rep];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int w = w0 + j < W32 ? w0 + j : W32 - 1;
+            const u32 v = (w == W32 - 1 ? lastvalid : 0xFFFFFFFFu) & ~cmask[w];
+            diff |= ((ma[j] ^ flip) ^ (mr[j] ^ rflip)) & v;
+        }
+    }
+    return diff == 0;
+}
+
+// n <= ST_MATCH_LDS_MAXN: one block per target, the table in LDS (8 bytes per slot: key = 15 tag bits | side | 16-bit id
+// of the first curve with that canonical mask; counter = members after the first, side 0 in the low half, side 1 in
+// the high half).  A curve that meets its own canonical mask joins the group with one LDS atomic on the counter; the
+// value it gets back is the group before it, so `members on the other side so far` summed over the joiners is exactly
+// count(side 0) * count(side 1).  Also writes the target's dirty bitmap and count for the pair kernel, and its total.
+constexpr i64 ST_MATCH_LDS_MAXN = 13107;                      // 16 384 slots (128 KiB) at a load of 0.8 at most
+constexpr int ST_ML_THREADS = 1024;
+static inline i64 strict_lds_slots(i64 n) {
+    i64 s = 64;
+    while (s * 4 < n * 5) s <<= 1;
+    return s;
+}
+__device__ __forceinline__ u64 strict_spread(u64 hf) {        // slot and tag bits from the payload (exact ones are not hashed yet)
+    u64 h = (hf >> 3) * 0x9E3779B97F4A7C15ull;
+    return h ^ (h >> 31);
+}
+__global__ __launch_bounds__(ST_ML_THREADS) void strict_match_lds_kernel(
+    const u32 *__restrict__ m32, const u64 *__restrict__ HF, i64 T, i64 n, const i64 *__restrict__ targets, i64 q0,
+    const u32 *__restrict__ xnan, const u32 *__restrict__ cmask, u32 *__restrict__ meta, u64 *__restrict__ dbits,
+    int slots, int whole_targets, u64 *__restrict__ out, int jcols) {
+    extern __shared__ u32 tabl[];                             // keys [slots] | counters [slots]
+    __shared__ u64 red[ST_ML_THREADS / 64][3];
+    const i64 b = blockIdx.x;
+    if (xnan[b]) return;
+    const i64 tg = targets ? targets[q0 + b] : q0 + b;
+    const int tid = threadIdx.x;
+    const int W32 = (int)((T + 31) / 32);
+    const u32 lastvalid = (T & 31) ? ((1u << (T & 31)) - 1u) : 0xFFFFFFFFu;
+    const u32 *mb = m32 + (size_t)b * 2 * W32 * n;
+    const u64 *hb = HF + (size_t)b * n;
+    u32 *cntl = tabl + slots;
+    for (int e = tid; e < 2 * slots; e += ST_ML_THREADS) tabl[e] = 0;
+    __syncthreads();
+    u64 acc = 0;
+    u32 z0 = 0, z1 = 0, nd = 0;
+    for (i64 a0 = 0; a0 < n; a0 += ST_ML_THREADS) {
+        const i64 a = a0 + tid;
+        const bool active = a < n && a != tg;
+        const u64 hf = a < n ? hb[a] : 0;
+        const bool clean = hf & 1;
+        const u32 side = (u32)(hf >> 2) & 1u;
+        const bool isdirty = active && !clean;
+        const u64 dw = __ballot(isdirty);
+        if ((tid & 63) == 0 && a0 + (tid & ~63) < n) dbits[(size_t)b * ((n + 63) / 64) + (a >> 6)] = dw;
+        nd += isdirty;
+        if (active && clean) {
+            if (!(hf & 2)) {                       // empty canonical mask: below throughout (side 0) / above throughout
+                z0 += side == 0;
+                z1 += side == 1;
+            } else {
+                const u64 h = strict_spread(hf);
+                const u32 tag = ((u32)(h >> 40) & 0x3FFFu) | 0x4000u;       // 15 bits, never zero
+                const u32 mine = (tag << 17) | (side << 16) | (u32)a;
+                int slot = (int)(h & (u64)(slots - 1));
+                for (int probe = 0; probe < slots; ++probe) {                // load <= 0.8: always ends early
+                    u32 cur = __hip_atomic_load(&tabl[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (cur == 0) {
+                        cur = atomicCAS(&tabl[slot], 0u, mine);
+                        if (cur == 0) break;
+                    }
+                    if ((cur >> 17) == tag) {
+                        const i64 rep = (i64)(cur & 0xFFFFu);
+                        const u64 hr = hb[rep];
+                        if (strict_same_canonical(mb, n, W32, lastvalid, cmask, a, hf, rep, hr)) {
+                            const u32 rside = (cur >> 16) & 1u;
+                            const u32 old = atomicAdd(&cntl[slot], side ? 0x10000u : 1u);
+                            acc += side ? (old & 0xFFFFu) + (rside == 0) : (old >> 16) + (rside == 1);
+                            break;
+                        }
+                    }
+                    slot = (slot + 1) & (slots - 1);
+                }
+            }
+        }
+    }
+    u64 r0 = acc, r1 = ((u64)z0 << 32) | z1, r2 = nd;
+    for (int o = 32; o > 0; o >>= 1) {
+        r0 += __shfl_down(r0, o);
+        r1 += __shfl_down(r1, o);
+        r2 += __shfl_down(r2, o);
+    }
+    if ((tid & 63) == 0) { red[tid >> 6][0] = r0; red[tid >> 6][1] = r1; red[tid >> 6][2] = r2; }
+    __syncthreads();
+    if (tid == 0) {
+        u64 t0 = 0, t1 = 0, t2 = 0;
+        for (int k = 0; k < ST_ML_THREADS / 64; ++k) { t0 += red[k][0]; t1 += red[k][1]; t2 += red[k][2]; }
+        meta[b * 4] = (u32)t2;
+        // with whole_targets the pair kernel that follows counts ALL pairs of a target that has dirty curves
+        if (!(whole_targets && t2)) out[(q0 + b) * jcols] = t0 + (t1 >> 32) * (t1 & 0xFFFFFFFFull);
+    }
+}
+
+// n > ST_MATCH_LDS_MAXN: the table in global memory (64-bit keys: 48 tag bits | id; two counters per slot).
 // grid = (ceil(n / 256), nb)
 __global__ __launch_bounds__(ST_THREADS) void strict_match_insert_kernel(
-    const u32 *__restrict__ m32, i64 T, i64 n, const i64 *__restrict__ targets, i64 q0, const u32 *__restrict__ xnan,
-    const u32 *__restrict__ cmask, u32 *__restrict__ meta, u64 *__restrict__ dbits, unsigned long long *__restrict__ keys,
-    u32 *__restrict__ cnt, i64 slots) {
+    const u32 *__restrict__ m32, const u64 *__restrict__ HF, i64 T, i64 n, const i64 *__restrict__ targets, i64 q0,
+    const u32 *__restrict__ xnan, const u32 *__restrict__ cmask, u32 *__restrict__ meta, u64 *__restrict__ dbits,
+    unsigned long long *__restrict__ keys, u32 *__restrict__ cnt, i64 slots) {
     const i64 b = blockIdx.y;
     if (xnan[b]) return;
     const i64 tg = targets ? targets[q0 + b] : q0 + b;
@@ -398,43 +594,9 @@ __global__ __launch_bounds__(ST_THREADS) void strict_match_insert_kernel(
     const int W32 = (int)((T + 31) / 32);
     const u32 lastvalid = (T & 31) ? ((1u << (T & 31)) - 1u) : 0xFFFFFFFFu;
     const u32 *mb = m32 + (size_t)b * 2 * W32 * n;
-    // the first timepoint that counts decides the side of the canonical form (wave-uniform scan of cmask)
-    int wf = 0;
-    u32 vf = 0;
-    for (; wf < W32; ++wf) {
-        vf = (wf == W32 - 1 ? lastvalid : 0xFFFFFFFFu) & ~cmask[wf];
-        if (vf) break;
-    }
-    // nothing is kept per word: the curve's words are read (coalesced, L2-resident) once for the hash and again only
-    // when a key with its hash turns up
-    bool clean = vf != 0;                                    // every row constant: all curves tie everywhere, pair kernel
-    u32 side = 0, flip = 0;
-    if (vf) {
-        side = (mb[(size_t)wf * n + a] >> (__ffs((int)vf) - 1)) & 1u;   // canonical form: the mask or its complement,
-        flip = side ? 0xFFFFFFFFu : 0u;                                  // whichever is 0 at that timepoint
-    }
-    u64 h = 0x9E3779B97F4A7C15ull;
-    u32 any = 0;
-    for (int w0 = 0; w0 < W32; w0 += 8) {
-        u32 un[8], dn[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {                         // sixteen loads in flight
-            const int w = w0 + j < W32 ? w0 + j : W32 - 1;
-            un[j] = mb[(size_t)w * n + a];
-            dn[j] = mb[(size_t)(W32 + w) * n + a];
-        }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int w = w0 + j;
-            if (w < W32) {
-                const u32 v = (w == W32 - 1 ? lastvalid : 0xFFFFFFFFu) & ~cmask[w];
-                clean &= ((un[j] ^ dn[j]) & v) == v && ((un[j] & dn[j]) == 0);   // above or below, not both (NaN), wherever it counts
-                const u32 cw = (un[j] ^ flip) & v;
-                any |= cw;
-                h = strict_mix(h, cw);
-            }
-        }
-    }
+    const u64 hf = HF[(size_t)b * n + a];
+    const bool clean = hf & 1;
+    const u32 side = (u32)(hf >> 2) & 1u;
     // dirty curves: one bit each for the pair kernel (this wave owns word a / 64 of the target's bitmap), and their
     // number -- one atomic per wave, with ties nearly every lane is dirty
     {
@@ -450,17 +612,16 @@ __global__ __launch_bounds__(ST_THREADS) void strict_match_insert_kernel(
     // the empty canonical mask -- curves below the target throughout (side 0) or above it throughout (side 1) -- is the
     // one big group of banded data: counted per wave with two ballots instead of n atomics on one table slot
     {
-        const u64 z0 = __ballot(any == 0 && side == 0), z1 = __ballot(any == 0 && side == 1);
-        if (any == 0) {
+        const bool empty = !(hf & 2);
+        const u64 z0 = __ballot(empty && side == 0), z1 = __ballot(empty && side == 1);
+        if (empty) {
             const int lane = threadIdx.x & 63;
             if (z0 && lane == __ffsll((long long)z0) - 1) atomicAdd(&meta[b * 4 + 1], (u32)__popcll(z0));
             if (z1 && lane == __ffsll((long long)z1) - 1) atomicAdd(&meta[b * 4 + 2], (u32)__popcll(z1));
             return;
         }
     }
-    h ^= h >> 32;
-    h *= 0xc4ceb9fe1a85ec53ull;
-    h ^= h >> 33;
+    const u64 h = strict_spread(hf);
     const u64 tag = (h >> 16) | ((u64)1 << 47);               // 48 bits, never zero
     const unsigned long long mine = (tag << 16) | (u64)a;
     unsigned long long *kb = keys + (size_t)b * slots;
@@ -473,16 +634,8 @@ __global__ __launch_bounds__(ST_THREADS) void strict_match_insert_kernel(
             if (cur == 0) break;
         }
         if ((cur >> 16) == tag) {
-            // the first claimant's canonical mask against this curve's, word by word
             const i64 rep = (i64)(cur & 0xFFFF);
-            const u32 rflip = ((mb[(size_t)wf * n + rep] >> (__ffs((int)vf) - 1)) & 1u) ? 0xFFFFFFFFu : 0u;
-            bool same = true;
-#pragma unroll 1
-            for (int w = 0; w < W32 && same; ++w) {
-                const u32 v = (w == W32 - 1 ? lastvalid : 0xFFFFFFFFu) & ~cmask[w];
-                same = ((mb[(size_t)w * n + a] ^ flip) & v) == ((mb[(size_t)w * n + rep] ^ rflip) & v);
-            }
-            if (same) break;
+            if (strict_same_canonical(mb, n, W32, lastvalid, cmask, a, hf, rep, HF[(size_t)b * n + rep])) break;
         }
         slot = (slot + 1) & (slots - 1);
     }
@@ -568,7 +721,10 @@ int launch_bd_strict(const double *Y, i64 T, i64 n, const i64 *targets, i64 m, i
     unsigned char *tab = (unsigned char *)cv.take((size_t)B * (slots * 16 + 16 + dwords * 8));
     u32 *cmask = (u32 *)cv.take((size_t)((T + 31) / 32) * 4);
     double *Yt = (double *)cv.take((size_t)B * ((T + 31) / 32) * 256);
-    if (!masks || !xnan || !tab || !cmask || !Yt) return fail(SD_ERR_WORKSPACE, "strict-depth workspace too small");
+    u64 *HF = (u64 *)cv.take((size_t)B * n * 8);                                    // hash + flags per (target, curve)
+    if (!masks || !xnan || !tab || !cmask || !Yt || !HF) return fail(SD_ERR_WORKSPACE, "strict-depth workspace too small");
+    // cross-check builds, SD_STRICT_GLOBAL_TABLE = 1: the global-memory table (the route of n > 16 384) at any n
+    const bool lds_match = match && n <= ST_MATCH_LDS_MAXN && xswitch("SD_STRICT_GLOBAL_TABLE") != 1;
     u64 *dbits = (u64 *)(tab + (size_t)B * (slots * 16 + 16));
     unsigned long long *keys = (unsigned long long *)tab;
     u32 *cnt = (u32 *)(tab + (size_t)B * slots * 8);
@@ -598,12 +754,23 @@ int launch_bd_strict(const double *Y, i64 T, i64 n, const i64 *targets, i64 m, i
                                xnan);
             hipLaunchKernelGGL(strict_masks2_kernel, g1b, dim3(ST_THREADS), 0, s, Y, (const double *)Yt, T, n, nb, (u32 *)masks);
             if (match) {
-                SD_HIP(hipMemsetAsync(tab, 0, (size_t)B * (slots * 16 + 16 + dwords * 8), s));
-                hipLaunchKernelGGL(strict_match_insert_kernel, g1, dim3(ST_THREADS), 0, s, (const u32 *)masks, T, n, targets, q0,
-                                   xnan, (const u32 *)cmask, dirty, dbits, keys, cnt, slots);
-                hipLaunchKernelGGL(strict_match_total_kernel,
-                                   dim3((unsigned)nb, (unsigned)((slots + ST_TOTAL_CHUNK - 1) / ST_TOTAL_CHUNK)), dim3(ST_THREADS), 0,
-                                   s, (const u32 *)cnt, slots, q0, xnan, (const u32 *)dirty, gen2 ? 0 : 1, out, jcols);
+                hipLaunchKernelGGL(strict_hash_kernel, g1, dim3(ST_THREADS), 0, s, (const u32 *)masks, T, n, xnan, (const u32 *)cmask, HF);
+                if (lds_match) {
+                    SD_HIP(hipMemsetAsync(dirty, 0, (size_t)B * 16, s));
+                    const i64 lslots = strict_lds_slots(n);
+                    const size_t tb = (size_t)lslots * 8;
+                    SD_HIP(hipFuncSetAttribute((const void *)strict_match_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tb));
+                    hipLaunchKernelGGL(strict_match_lds_kernel, dim3((unsigned)nb), dim3(ST_ML_THREADS), tb, s, (const u32 *)masks,
+                                       (const u64 *)HF, T, n, targets, q0, xnan, (const u32 *)cmask, dirty, dbits, (int)lslots,
+                                       gen2 ? 0 : 1, out, jcols);
+                } else {
+                    SD_HIP(hipMemsetAsync(tab, 0, (size_t)B * (slots * 16 + 16 + dwords * 8), s));
+                    hipLaunchKernelGGL(strict_match_insert_kernel, g1, dim3(ST_THREADS), 0, s, (const u32 *)masks, (const u64 *)HF, T, n,
+                                       targets, q0, xnan, (const u32 *)cmask, dirty, dbits, keys, cnt, slots);
+                    hipLaunchKernelGGL(strict_match_total_kernel,
+                                       dim3((unsigned)nb, (unsigned)((slots + ST_TOTAL_CHUNK - 1) / ST_TOTAL_CHUNK)), dim3(ST_THREADS),
+                                       0, s, (const u32 *)cnt, slots, q0, xnan, (const u32 *)dirty, gen2 ? 0 : 1, out, jcols);
+                }
                 gate = dirty;
             }
             if (gen2) {

@@ -430,6 +430,8 @@ def test_strict_complement_matching_vs_oracle(eng, oracle, xcheck, shape):
     assert (eng.bd_strict_counts(X, tg)[:, 0] == want[tg]).all()
     with xcheck(SD_STRICT_NOMATCH=1):
         assert (eng.bd_strict_counts(X)[:, 0] == want).all()
+    with xcheck(SD_STRICT_GLOBAL_TABLE=1):           # the table of n > 16 384, in global memory
+        assert (eng.bd_strict_counts(X)[:, 0] == want).all()
 
 
 def test_strict_complement_matching_random_walks_vs_pair_kernel(eng, xcheck):
@@ -472,10 +474,38 @@ def test_strict_matching_with_common_values_and_sparse_ties(eng, oracle, xcheck,
     assert (gotb == wantb).all()
     with xcheck(SD_STRICT_NOMATCH=1):
         assert (eng.bd_strict_counts(Xb)[:, 0] == wantb).all()
+    with xcheck(SD_STRICT_GLOBAL_TABLE=1):
+        assert (eng.bd_strict_counts(Xb)[:, 0] == wantb).all()
     # every row constant: every pair contains every target
     Xc = np.tile(rng.normal(size=(T, 1)), (1, 9))
     assert (eng.bd_strict_counts(Xc)[:, 0] == 28).all()
     assert (oracle.bd_strict_counts(Xc) == 28).all()
+
+
+def test_strict_matching_groups_with_many_members(eng, oracle, xcheck):
+    """Several curves with the SAME crossing pattern relative to a target, on both sides: the group counters
+    (count(side 0) * count(side 1) per canonical mask) rather than groups of one."""
+    rng = np.random.default_rng(77)
+    T, n = 96, 60
+    tgt = rng.normal(size=T)
+    sign = np.where(rng.random(T) < 0.5, 1.0, -1.0)           # one crossing pattern
+    X = np.empty((T, n))
+    X[:, 0] = tgt
+    for i in range(1, 8):
+        X[:, i] = tgt + sign * (0.1 + 0.05 * i)               # seven curves following the pattern
+    for i in range(8, 13):
+        X[:, i] = tgt - sign * (0.2 + 0.03 * i)               # five following its complement
+    sign2 = np.where(rng.random(T) < 0.5, 1.0, -1.0)
+    for i in range(13, 16):
+        X[:, i] = tgt + sign2 * (0.15 + 0.01 * i)
+    for i in range(16, 20):
+        X[:, i] = tgt - sign2 * (0.3 + 0.01 * i)
+    X[:, 20:] = tgt[:, None] + rng.normal(size=(T, n - 20)) * 2.0 + np.linspace(-30, 30, n - 20)[None, :]
+    want = oracle.bd_strict_counts(X)
+    assert want[0] >= 7 * 5 + 3 * 4
+    assert (eng.bd_strict_counts(X)[:, 0] == want).all()
+    with xcheck(SD_STRICT_GLOBAL_TABLE=1):
+        assert (eng.bd_strict_counts(X)[:, 0] == want).all()
 
 
 def test_strict_J3_J4_vs_literal_enumeration(eng, oracle):
