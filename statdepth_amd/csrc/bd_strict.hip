@@ -48,7 +48,7 @@ size_t bd_strict_workspace_bytes(i64 T, i64 n, i64 m, int J) {
     return align_up((size_t)b * n * 2 * strict_words(T) * 8, 256) + align_up((size_t)b * 4, 256) +
            align_up((size_t)b * (strict_table_slots(n) * 16 + 16 + ((n + 63) / 64) * 8), 256) +
            align_up((size_t)((T + 31) / 32) * 4, 256) + align_up((size_t)b * ((T + 31) / 32) * 256, 256) +
-           align_up((size_t)b * n * 8, 256) + 2048;
+           align_up((size_t)b * n * 8, 256) + align_up((size_t)(b + 1) * 4, 256) + 2048;
 }
 
 // masks[b][i][0..W) = UN, masks[b][i][W..2W) = DN
@@ -301,20 +301,16 @@ __global__ __launch_bounds__(ST_THREADS) void strict_hash_kernel(const u32 *__re
     HF[(size_t)b * n + a] = (payload << 4) | ((exact ? 1u : 0u) << 3) | (side << 2) | ((nz ? 1u : 0u) << 1) | (clean ? 1u : 0u);
 }
 
-// grid = (a tiles, b chunks, batch)
-__global__ __launch_bounds__(ST_THREADS) void strict_pairs2_kernel(
-    const u32 *__restrict__ m32, i64 T, i64 n, const i64 *__restrict__ targets, i64 q0,
-    const u32 *__restrict__ xnan, const u32 *__restrict__ dirty, const u64 *__restrict__ dbits, u64 *__restrict__ out,
-    int jcols) {
+// one (a tile, b chunk) of target b; db = the target's dirty bitmap when matching has counted the clean-clean pairs
+__device__ __forceinline__ void strict_pairs2_target(const u32 *__restrict__ m32, i64 T, i64 n, const i64 *__restrict__ targets,
+                                                     i64 q0, const u64 *__restrict__ dbits, u64 *__restrict__ out, int jcols,
+                                                     const i64 b) {
     __shared__ u64 scratch[ST_THREADS / 64];
     __shared__ u32 orparts[ST_THREADS / 64][2][ST_SUB];   // per wave: OR of its quarter of partner j's UN / DN words
     __shared__ __attribute__((aligned(16))) u32 cm[ST_SUB][2 * ST_W32 + 4];   // partner j: UN words 0..31, DN words 0..31 (zero
                                                                                 // beyond W32); rows padded by 16 bytes: the survivors'
                                                                                 // per-lane rows fall on different banks
-    const i64 b = blockIdx.z;
     const i64 q = q0 + b;
-    if (xnan[b]) return;                       // NaN in the target: nothing is contained
-    if (dirty && dirty[b * 4] == 0) return;        // every curve is strictly above or below at every timepoint: counted by matching
     // with matching on, the pairs of two clean curves are counted there; here only pairs with a dirty member remain
     const u64 *db = dbits ? dbits + (size_t)b * ((n + 63) / 64) : nullptr;
     const i64 tg = targets ? targets[q] : q;
@@ -420,6 +416,26 @@ __global__ __launch_bounds__(ST_THREADS) void strict_pairs2_kernel(
     if (threadIdx.x == 0 && tot) atomicAdd(&out[q * jcols], tot);
 }
 
+// Without matching: grid = (a tiles, b chunks, nb), block z = target z.  With matching: grid.z is a fixed number of
+// layers that share out the batch's targets WITH dirty curves (dlist, *dcount: appended by the matching kernels) --
+// continuous data has none, and a grid over all targets would cost more in empty blocks than everything else here.
+constexpr int ST_PAIR_LAYERS = 32;
+__global__ __launch_bounds__(ST_THREADS) void strict_pairs2_kernel(
+    const u32 *__restrict__ m32, i64 T, i64 n, const i64 *__restrict__ targets, i64 q0,
+    const u32 *__restrict__ xnan, const u32 *__restrict__ dlist, const u32 *__restrict__ dcount,
+    const u64 *__restrict__ dbits, u64 *__restrict__ out, int jcols) {
+    if (!dlist) {
+        if (xnan[blockIdx.z]) return;              // NaN in the target: nothing is contained
+        strict_pairs2_target(m32, T, n, targets, q0, nullptr, out, jcols, (i64)blockIdx.z);
+        return;
+    }
+    const u32 cnt = *dcount;
+    for (u32 zi = blockIdx.z; zi < cnt; zi += gridDim.z) {
+        strict_pairs2_target(m32, T, n, targets, q0, dbits, out, jcols, (i64)dlist[zi]);
+        __syncthreads();                           // the target's shared arrays are reused by the next one
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // J = 2 by complement matching: O(n T) per target instead of O(n^2 T).
 // Call a curve CLEAN for a target when at every timepoint that counts it is strictly above or strictly below it (no
@@ -507,7 +523,7 @@ __device__ __forceinline__ u64 strict_spread(u64 hf) {        // slot and tag bi
 __global__ __launch_bounds__(ST_ML_THREADS) void strict_match_lds_kernel(
     const u32 *__restrict__ m32, const u64 *__restrict__ HF, i64 T, i64 n, const i64 *__restrict__ targets, i64 q0,
     const u32 *__restrict__ xnan, const u32 *__restrict__ cmask, u32 *__restrict__ meta, u64 *__restrict__ dbits,
-    int slots, int whole_targets, u64 *__restrict__ out, int jcols) {
+    u32 *__restrict__ dlist, u32 *__restrict__ dcount, int slots, int whole_targets, u64 *__restrict__ out, int jcols) {
     extern __shared__ u32 tabl[];                             // keys [slots] | counters [slots]
     __shared__ u64 red[ST_ML_THREADS / 64][3];
     const i64 b = blockIdx.x;
@@ -575,6 +591,7 @@ __global__ __launch_bounds__(ST_ML_THREADS) void strict_match_lds_kernel(
         u64 t0 = 0, t1 = 0, t2 = 0;
         for (int k = 0; k < ST_ML_THREADS / 64; ++k) { t0 += red[k][0]; t1 += red[k][1]; t2 += red[k][2]; }
         meta[b * 4] = (u32)t2;
+        if (t2) dlist[atomicAdd(dcount, 1u)] = (u32)b;        // the pair kernel's work list
         // with whole_targets the pair kernel that follows counts ALL pairs of a target that has dirty curves
         if (!(whole_targets && t2)) out[(q0 + b) * jcols] = t0 + (t1 >> 32) * (t1 & 0xFFFFFFFFull);
     }
@@ -646,10 +663,11 @@ __global__ __launch_bounds__(ST_THREADS) void strict_match_insert_kernel(
 constexpr int ST_TOTAL_CHUNK = 4096;
 __global__ __launch_bounds__(ST_THREADS) void strict_match_total_kernel(
     const u32 *__restrict__ cnt, i64 slots, i64 q0, const u32 *__restrict__ xnan, const u32 *__restrict__ meta,
-    int whole_targets, u64 *__restrict__ out, int jcols) {
+    u32 *__restrict__ dlist, u32 *__restrict__ dcount, int whole_targets, u64 *__restrict__ out, int jcols) {
     __shared__ u64 scratch[ST_THREADS / 64];
     const i64 b = blockIdx.x;
     if (xnan[b]) return;
+    if (blockIdx.y == 0 && threadIdx.x == 0 && meta[b * 4] != 0) dlist[atomicAdd(dcount, 1u)] = (u32)b;   // the pair kernel's work list
     if (whole_targets && meta[b * 4] != 0) return;   // the pair kernel that follows counts ALL pairs of such a target
     const uint2 *cb = reinterpret_cast<const uint2 *>(cnt) + (size_t)b * slots;
     const i64 i0 = (i64)blockIdx.y * ST_TOTAL_CHUNK;
@@ -722,7 +740,10 @@ int launch_bd_strict(const double *Y, i64 T, i64 n, const i64 *targets, i64 m, i
     u32 *cmask = (u32 *)cv.take((size_t)((T + 31) / 32) * 4);
     double *Yt = (double *)cv.take((size_t)B * ((T + 31) / 32) * 256);
     u64 *HF = (u64 *)cv.take((size_t)B * n * 8);                                    // hash + flags per (target, curve)
-    if (!masks || !xnan || !tab || !cmask || !Yt || !HF) return fail(SD_ERR_WORKSPACE, "strict-depth workspace too small");
+    u32 *dlist = (u32 *)cv.take((size_t)(B + 1) * 4);                               // dirty targets of the batch | their number
+    if (!masks || !xnan || !tab || !cmask || !Yt || !HF || !dlist)
+        return fail(SD_ERR_WORKSPACE, "strict-depth workspace too small");
+    u32 *dcount = dlist + B;
     // cross-check builds, SD_STRICT_GLOBAL_TABLE = 1: the global-memory table (the route of n > 16 384) at any n
     const bool lds_match = match && n <= ST_MATCH_LDS_MAXN && xswitch("SD_STRICT_GLOBAL_TABLE") != 1;
     u64 *dbits = (u64 *)(tab + (size_t)B * (slots * 16 + 16));
@@ -757,25 +778,36 @@ int launch_bd_strict(const double *Y, i64 T, i64 n, const i64 *targets, i64 m, i
                 hipLaunchKernelGGL(strict_hash_kernel, g1, dim3(ST_THREADS), 0, s, (const u32 *)masks, T, n, xnan, (const u32 *)cmask, HF);
                 if (lds_match) {
                     SD_HIP(hipMemsetAsync(dirty, 0, (size_t)B * 16, s));
+                    SD_HIP(hipMemsetAsync(dcount, 0, 4, s));
                     const i64 lslots = strict_lds_slots(n);
                     const size_t tb = (size_t)lslots * 8;
                     SD_HIP(hipFuncSetAttribute((const void *)strict_match_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tb));
                     hipLaunchKernelGGL(strict_match_lds_kernel, dim3((unsigned)nb), dim3(ST_ML_THREADS), tb, s, (const u32 *)masks,
-                                       (const u64 *)HF, T, n, targets, q0, xnan, (const u32 *)cmask, dirty, dbits, (int)lslots,
-                                       gen2 ? 0 : 1, out, jcols);
+                                       (const u64 *)HF, T, n, targets, q0, xnan, (const u32 *)cmask, dirty, dbits, dlist, dcount,
+                                       (int)lslots, gen2 ? 0 : 1, out, jcols);
                 } else {
                     SD_HIP(hipMemsetAsync(tab, 0, (size_t)B * (slots * 16 + 16 + dwords * 8), s));
+                    SD_HIP(hipMemsetAsync(dcount, 0, 4, s));
                     hipLaunchKernelGGL(strict_match_insert_kernel, g1, dim3(ST_THREADS), 0, s, (const u32 *)masks, (const u64 *)HF, T, n,
                                        targets, q0, xnan, (const u32 *)cmask, dirty, dbits, keys, cnt, slots);
                     hipLaunchKernelGGL(strict_match_total_kernel,
                                        dim3((unsigned)nb, (unsigned)((slots + ST_TOTAL_CHUNK - 1) / ST_TOTAL_CHUNK)), dim3(ST_THREADS),
-                                       0, s, (const u32 *)cnt, slots, q0, xnan, (const u32 *)dirty, gen2 ? 0 : 1, out, jcols);
+                                       0, s, (const u32 *)cnt, slots, q0, xnan, (const u32 *)dirty, dlist, dcount, gen2 ? 0 : 1, out, jcols);
                 }
                 gate = dirty;
             }
             if (gen2) {
-                hipLaunchKernelGGL(strict_pairs2_kernel, g2, dim3(ST_THREADS), 0, s, (const u32 *)masks, T, n, targets, q0, xnan,
-                                   gate, gate ? (const u64 *)dbits : (const u64 *)nullptr, out, jcols);
+                if (gate) {
+                    i64 layers = 4096 / ((i64)g2.x * g2.y);            // about 4 096 blocks in all, 32 layers at least
+                    if (layers < ST_PAIR_LAYERS) layers = ST_PAIR_LAYERS;
+                    if (layers > nb) layers = nb;
+                    dim3 g2m(g2.x, g2.y, (unsigned)layers);
+                    hipLaunchKernelGGL(strict_pairs2_kernel, g2m, dim3(ST_THREADS), 0, s, (const u32 *)masks, T, n, targets, q0, xnan,
+                                       (const u32 *)dlist, (const u32 *)dcount, (const u64 *)dbits, out, jcols);
+                } else {
+                    hipLaunchKernelGGL(strict_pairs2_kernel, g2, dim3(ST_THREADS), 0, s, (const u32 *)masks, T, n, targets, q0, xnan,
+                                       (const u32 *)nullptr, (const u32 *)nullptr, (const u64 *)nullptr, out, jcols);
+                }
                 SD_HIP(hipGetLastError());
                 continue;
             }
