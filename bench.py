@@ -149,6 +149,20 @@ def extras_single_gpu(torch, dev, stream, lib, check, ALGOS, oracle, reps=10):
     assert (res.cpu().numpy()[tg, 0] == oracle.bd_strict_counts(Xs, tg)).all(), "strict"
     out["strict_2000x1000"] = {"workload": "strict band depth J=2, 2000 banded curves x 1000 timepoints", "ms": ms,
                                "pair_tests_per_s": n * (n - 1) * (n - 2) / 2 / (ms * 1e-3), "checked_targets": len(tg)}
+    # ... and at config 2's size: 10 000 random walks x 1 000 timepoints, every target
+    Xw = np.random.default_rng(12).normal(size=(1000, 10000)).cumsum(axis=0)
+    Xd = torch.from_numpy(Xw).to(dev)
+    T, n = Xw.shape
+    res = torch.empty((n, 1), dtype=torch.int64, device=dev)
+    wsb = lib.sd_bd_strict_workspace_bytes(T, n, n, 1, n)
+    ws = torch.empty(int(wsb), dtype=torch.uint8, device=dev)
+    _, ms = timed(lambda _: check(lib.sd_bd_strict_counts(Xd.data_ptr(), T, n, n, 1, 0, n, res.data_ptr(), ws.data_ptr(), wsb,
+                                                         stream.cuda_stream)), 2, 1, stream, torch)
+    tg = np.array([0, 2500, 5000, 9999])
+    assert (res.cpu().numpy()[tg, 0] == oracle.bd_strict_counts(Xw, tg)).all(), "strict 10000"
+    out["strict_10000x1000"] = {"workload": "strict band depth J=2, 10000 random walks x 1000 timepoints, every target", "ms": ms,
+                                "pair_tests_per_s": n * (n - 1) * (n - 2) / 2 / (ms * 1e-3), "checked_targets": len(tg)}
+    del Xd, res, ws
     # L1 depth and sampled simplicial depth
     P = np.random.default_rng(1237).normal(size=(100000, 3))
     Pd = torch.from_numpy(P).to(dev)

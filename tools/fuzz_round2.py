@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Fuzz of the entry points added in round 2 against the CPU oracle (GPU box): componentwise band containment (K6),
-external / blocked point-cloud targets (simplex, L1), two-limb totals.  usage: fuzz_round2.py [cases] [seed]"""
+external / blocked point-cloud targets (simplex, L1), strict band depth by complement matching, two-limb totals.  usage: fuzz_round2.py [cases] [seed]"""
 import math, os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -38,6 +38,27 @@ for c in range(cases):
     for i, b in enumerate(blocks):
         if cnt[i] != oracle.pointcloud_simplex_counts(F[b], [len(b) - 1])[0]:
             bad += 1; print(f"SUBSET MISMATCH case {c}: n={n} d={d} block {i}", flush=True)
+    # ---- strict band depth: complement matching with every kind of curve mixed in ----
+    T = int(rng.choice([3, 17, 32, 33, 64, 95, 130, 257, 1025, 1100])); n = int(rng.integers(4, 260))
+    if rng.random() < 0.5:
+        X = np.sort(rng.normal(size=n))[None, :] * rng.choice([0.5, 3.0]) + rng.normal(size=(T, n)) * rng.choice([0.05, 0.5])
+    else:
+        X = rng.normal(size=(T, n)).cumsum(axis=0)
+    for _ in range(int(rng.integers(0, 4))):                  # groups sharing a crossing pattern with some curve, both sides
+        base = int(rng.integers(0, n)); sign = np.where(rng.random(T) < 0.5, 1.0, -1.0)
+        for i in rng.choice(n, size=min(n, int(rng.integers(1, 6))), replace=False):
+            if i != base: X[:, i] = X[:, base] + sign * rng.choice([-1.0, 1.0]) * rng.uniform(0.01, 0.5)
+    if rng.random() < 0.3: X[rng.integers(0, T)] = 0.25       # a constant row
+    if rng.random() < 0.2: X[0] = X[0, 0]
+    if rng.random() < 0.3:                                    # sparse ties
+        for _ in range(int(rng.integers(1, 5))):
+            i, j, t = rng.integers(0, n), rng.integers(0, n), rng.integers(0, T); X[t, i] = X[t, j]
+    if rng.random() < 0.15: X[:, rng.integers(0, n)] = X[:, rng.integers(0, n)]
+    if rng.random() < 0.15: X[rng.integers(0, T), rng.integers(0, n)] = np.nan
+    if rng.random() < 0.1: X = np.round(X, 1)                 # ties everywhere
+    tg = rng.choice(n, size=min(n, 12), replace=False)
+    if not (engine.bd_strict_counts(X, tg, 2)[:, 0] == oracle.bd_strict_counts(X, tg)).all():
+        bad += 1; print(f"STRICT MISMATCH case {c}: n={n} T={T}", flush=True)
     # ---- two-limb totals ----
     if c % 10 == 0:
         n = int(rng.integers(1500, 3200)); J = 6; T = int(rng.integers(12, 40))
