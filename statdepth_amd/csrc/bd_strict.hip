@@ -19,6 +19,9 @@
 
 namespace sd {
 
+int launch_rank_bucket_image(const double *Y, i64 n, i64 row0, i64 rows, u32 *AB, u32 *nnan, hipStream_t s);   // mbd_rank_bucket.hip
+constexpr i64 ST_RANK_MAXN = 16384;          // what the bucket kernel covers
+
 constexpr int ST_THREADS = 256;
 constexpr int ST_WREG = 16;          // mask words kept in registers (T <= 1024)
 
@@ -48,7 +51,8 @@ size_t bd_strict_workspace_bytes(i64 T, i64 n, i64 m, int J) {
     return align_up((size_t)b * n * 2 * strict_words(T) * 8, 256) + align_up((size_t)b * 4, 256) +
            align_up((size_t)b * (strict_table_slots(n) * 16 + 16 + ((n + 63) / 64) * 8), 256) +
            align_up((size_t)((T + 31) / 32) * 4, 256) + align_up((size_t)b * ((T + 31) / 32) * 256, 256) +
-           align_up((size_t)b * n * 8, 256) + align_up((size_t)(b + 1) * 4, 256) + 2048;
+           align_up((size_t)b * n * 8, 256) + align_up((size_t)(b + 1) * 4, 256) +
+           (n <= ST_RANK_MAXN ? align_up((size_t)T * n * 4, 256) + align_up((size_t)T * 4, 256) : 0) + 2560;
 }
 
 // masks[b][i][0..W) = UN, masks[b][i][W..2W) = DN
@@ -210,6 +214,62 @@ __global__ __launch_bounds__(ST_THREADS) void strict_masks2_kernel(
 #pragma unroll
         for (int t = 0; t < 32; ++t) {                              // no branch in here: the loads issue together
             const double q = xq[t];
+            un |= (x[t] > q) ? (1u << t) : 0u;
+            dn |= (x[t] < q) ? (1u << t) : 0u;
+        }
+        if (i < n) {
+            m32[((size_t)b * 2 * W32 + k) * n + i] = un & valid;
+            m32[((size_t)b * 2 * W32 + W32 + k) * n + i] = dn & valid;
+        }
+    }
+}
+
+// The same masks from INTEGER ranks (n <= 16 384).  The bucket kernel's image mode (mbd_rank_bucket.hip) turns the
+// matrix into R[t][i] = B | A << 16 with B = number of curves strictly below curve i at t (0xFFFFFFFF: NaN): B is order-
+// and tie-preserving (x_i > x_q <=> B_i > B_q, equal values share B), costs one pass of the headline kernel (0.07 ms at
+// 10 000 x 1 000), and makes the mask kernel's compares 32-bit (full rate; the fp64 ones run at half) on half the
+// registers.  Rt: the batch's targets gathered as in strict_gather_targets_kernel (B only, zero beyond T).
+constexpr u32 ST_RANK_NAN = 0xFFFFFFFFu;
+__global__ __launch_bounds__(ST_THREADS) void strict_gather_rank_targets_kernel(
+    const u32 *__restrict__ R, i64 T, i64 n, const i64 *__restrict__ targets, i64 q0, u32 *__restrict__ Rt,
+    u32 *__restrict__ xnan) {
+    const i64 b = blockIdx.x;
+    const i64 tg = targets ? targets[q0 + b] : q0 + b;
+    const i64 Tp = ((T + 31) / 32) * 32;
+    bool isn = false;
+    for (i64 t = threadIdx.x; t < Tp; t += ST_THREADS) {
+        const u32 w = t < T ? R[t * n + tg] : 0u;
+        isn |= w == ST_RANK_NAN;
+        Rt[b * Tp + t] = w & 0xFFFFu;
+    }
+    if (__syncthreads_or(isn) && threadIdx.x == 0) xnan[b] = 1;
+}
+
+// grid = (ceil(n / 256), W32, ceil(nb / ST_TG))
+__global__ __launch_bounds__(ST_THREADS) void strict_masks_rank_kernel(
+    const u32 *__restrict__ R, const u32 *__restrict__ Rt, i64 T, i64 n, i64 nb, u32 *__restrict__ m32) {
+    const i64 i = (i64)blockIdx.x * ST_THREADS + threadIdx.x;
+    const int k = blockIdx.y;
+    const int W32 = (int)((T + 31) / 32);
+    const i64 t0 = (i64)k * 32;
+    const int tl = (int)(T - t0 < 32 ? T - t0 : 32);
+    const u32 valid = tl == 32 ? 0xFFFFFFFFu : ((1u << tl) - 1u);
+    u32 x[32];
+    u32 nanbits = 0;
+#pragma unroll
+    for (int t = 0; t < 32; ++t) {
+        const u32 w = (i < n && t < tl) ? R[(t0 + t) * n + i] : 0u;
+        const bool isn = w == ST_RANK_NAN;
+        nanbits |= isn ? (1u << t) : 0u;
+        x[t] = isn ? 0u : (w & 0xFFFFu);
+    }
+    const i64 bend = ((i64)blockIdx.z + 1) * ST_TG < nb ? ((i64)blockIdx.z + 1) * ST_TG : nb;
+    for (i64 b = (i64)blockIdx.z * ST_TG; b < bend; ++b) {
+        const u32 *__restrict__ xq = Rt + (b * W32 + k) * 32;      // wave-uniform, contiguous: wide scalar loads
+        u32 un = nanbits, dn = nanbits;
+#pragma unroll
+        for (int t = 0; t < 32; ++t) {
+            const u32 q = xq[t];
             un |= (x[t] > q) ? (1u << t) : 0u;
             dn |= (x[t] < q) ? (1u << t) : 0u;
         }
@@ -744,6 +804,14 @@ int launch_bd_strict(const double *Y, i64 T, i64 n, const i64 *targets, i64 m, i
     if (!masks || !xnan || !tab || !cmask || !Yt || !HF || !dlist)
         return fail(SD_ERR_WORKSPACE, "strict-depth workspace too small");
     u32 *dcount = dlist + B;
+    // cross-check builds, SD_STRICT_FP64_MASKS = 1: masks from the fp64 values at any n
+    const bool rankmasks = n >= 2 && n <= ST_RANK_MAXN && J == 2 && xswitch("SD_STRICT_V1") != 1 && xswitch("SD_STRICT_FP64_MASKS") != 1;
+    u32 *R = nullptr, *rnan = nullptr;
+    if (rankmasks) {
+        R = (u32 *)cv.take((size_t)T * n * 4);
+        rnan = (u32 *)cv.take((size_t)T * 4);
+        if (!R || !rnan) return fail(SD_ERR_WORKSPACE, "strict-depth workspace too small");
+    }
     // cross-check builds, SD_STRICT_GLOBAL_TABLE = 1: the global-memory table (the route of n > 16 384) at any n
     const bool lds_match = match && n <= ST_MATCH_LDS_MAXN && xswitch("SD_STRICT_GLOBAL_TABLE") != 1;
     u64 *dbits = (u64 *)(tab + (size_t)B * (slots * 16 + 16));
@@ -759,6 +827,14 @@ int launch_bd_strict(const double *Y, i64 T, i64 n, const i64 *targets, i64 m, i
     }
     if (match)
         hipLaunchKernelGGL(strict_const_rows_kernel, dim3((unsigned)((T + 31) / 32)), dim3(ST_THREADS), 0, s, Y, T, n, cmask);
+    if (rankmasks) {
+        // the image launcher takes at most 2048 rows per workgroup
+        const i64 step = 2048 * 64;
+        for (i64 r0 = 0; r0 < T; r0 += step) {
+            int rc = launch_rank_bucket_image(Y, n, r0, T - r0 < step ? T - r0 : step, R + r0 * n, rnan + r0, s);
+            if (rc) return rc;
+        }
+    }
     for (i64 q0 = 0; q0 < m; q0 += B) {
         i64 nb = m - q0 < B ? m - q0 : B;
         SD_HIP(hipMemsetAsync(xnan, 0, (size_t)nb * 4, s));
@@ -771,9 +847,16 @@ int launch_bd_strict(const double *Y, i64 T, i64 n, const i64 *targets, i64 m, i
         if (gen2 || match) {
             // second generation: 32-bit words, word-major image (fits the same workspace: 2 W32 n u32 <= 2 W n u64)
             dim3 g1b((unsigned)((n + ST_THREADS - 1) / ST_THREADS), (unsigned)W32, (unsigned)((nb + ST_TG - 1) / ST_TG));
-            hipLaunchKernelGGL(strict_gather_targets_kernel, dim3((unsigned)nb), dim3(ST_THREADS), 0, s, Y, T, n, targets, q0, Yt,
-                               xnan);
-            hipLaunchKernelGGL(strict_masks2_kernel, g1b, dim3(ST_THREADS), 0, s, Y, (const double *)Yt, T, n, nb, (u32 *)masks);
+            if (rankmasks) {
+                hipLaunchKernelGGL(strict_gather_rank_targets_kernel, dim3((unsigned)nb), dim3(ST_THREADS), 0, s, (const u32 *)R, T, n,
+                                   targets, q0, (u32 *)Yt, xnan);
+                hipLaunchKernelGGL(strict_masks_rank_kernel, g1b, dim3(ST_THREADS), 0, s, (const u32 *)R, (const u32 *)Yt, T, n, nb,
+                                   (u32 *)masks);
+            } else {
+                hipLaunchKernelGGL(strict_gather_targets_kernel, dim3((unsigned)nb), dim3(ST_THREADS), 0, s, Y, T, n, targets, q0, Yt,
+                                   xnan);
+                hipLaunchKernelGGL(strict_masks2_kernel, g1b, dim3(ST_THREADS), 0, s, Y, (const double *)Yt, T, n, nb, (u32 *)masks);
+            }
             if (match) {
                 hipLaunchKernelGGL(strict_hash_kernel, g1, dim3(ST_THREADS), 0, s, (const u32 *)masks, T, n, xnan, (const u32 *)cmask, HF);
                 if (lds_match) {

@@ -432,6 +432,8 @@ def test_strict_complement_matching_vs_oracle(eng, oracle, xcheck, shape):
         assert (eng.bd_strict_counts(X)[:, 0] == want).all()
     with xcheck(SD_STRICT_GLOBAL_TABLE=1):           # the table of n > 16 384, in global memory
         assert (eng.bd_strict_counts(X)[:, 0] == want).all()
+    with xcheck(SD_STRICT_FP64_MASKS=1):             # masks from the values instead of the rank image (n > 16 384)
+        assert (eng.bd_strict_counts(X)[:, 0] == want).all()
 
 
 def test_strict_complement_matching_random_walks_vs_pair_kernel(eng, xcheck):
@@ -506,6 +508,35 @@ def test_strict_matching_groups_with_many_members(eng, oracle, xcheck):
     assert (eng.bd_strict_counts(X)[:, 0] == want).all()
     with xcheck(SD_STRICT_GLOBAL_TABLE=1):
         assert (eng.bd_strict_counts(X)[:, 0] == want).all()
+
+
+def test_strict_masks_from_ranks_with_nan_inf_and_ties(eng, oracle, xcheck):
+    """The mask kernel works on the bucket kernel's rank image (B = curves strictly below): NaN entries, +-inf, ties,
+    an all-NaN timepoint and an all-equal timepoint, against the oracle and against the fp64 mask kernel."""
+    rng = np.random.default_rng(5)
+    T, n = 70, 333
+    X = np.round(rng.normal(size=(T, n)).cumsum(axis=0), 1)
+    X[rng.random(X.shape) < 0.02] = np.nan
+    X[3, 10:20] = np.inf
+    X[5, 30:35] = -np.inf
+    X[7, 40] = np.inf
+    X[9, :] = np.nan
+    X[11, :] = 2.0
+    X[:, 50] = np.linspace(-3, 3, T)                  # NaN-free curves so that some targets count
+    X[:, 51] = X[:, 50] + 100.0
+    X[:, 52] = X[:, 50] - 100.0
+    X[9, 50:53] = [0.0, 100.0, -100.0]
+    want = oracle.bd_strict_counts(X)
+    got = eng.bd_strict_counts(X)[:, 0]
+    assert (got == want).all()
+    with xcheck(SD_STRICT_FP64_MASKS=1):
+        assert (eng.bd_strict_counts(X)[:, 0] == want).all()
+    Xi = X.copy()
+    Xi[9, :] = 1.0                                    # without the all-NaN timepoint more targets count
+    Xi[np.isnan(Xi)] = 0.5
+    wanti = oracle.bd_strict_counts(Xi)
+    assert wanti.sum() > 0
+    assert (eng.bd_strict_counts(Xi)[:, 0] == wanti).all()
 
 
 def test_strict_J3_J4_vs_literal_enumeration(eng, oracle):
