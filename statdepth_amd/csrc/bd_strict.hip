@@ -266,16 +266,19 @@ __global__ __launch_bounds__(ST_THREADS) void strict_masks_rank_kernel(
     const i64 bend = ((i64)blockIdx.z + 1) * ST_TG < nb ? ((i64)blockIdx.z + 1) * ST_TG : nb;
     for (i64 b = (i64)blockIdx.z * ST_TG; b < bend; ++b) {
         const u32 *__restrict__ xq = Rt + (b * W32 + k) * 32;      // wave-uniform, contiguous: wide scalar loads
-        u32 un = nanbits, dn = nanbits;
+        // ranks are < 2^16, so the sign bit of a difference IS the comparison; v_alignbit shifts it in from the right:
+        // two full-rate instructions per (timepoint, direction), no condition codes.  t runs down so that t = 0 ends
+        // in bit 0 (the 32 shifts push the initial value out).
+        u32 un = 0, dn = 0;
 #pragma unroll
-        for (int t = 0; t < 32; ++t) {
+        for (int t = 31; t >= 0; --t) {
             const u32 q = xq[t];
-            un |= (x[t] > q) ? (1u << t) : 0u;
-            dn |= (x[t] < q) ? (1u << t) : 0u;
+            un = __builtin_amdgcn_alignbit(un, q - x[t], 31);           // (un << 1) | (x > q)
+            dn = __builtin_amdgcn_alignbit(dn, x[t] - q, 31);           // (dn << 1) | (x < q)
         }
         if (i < n) {
-            m32[((size_t)b * 2 * W32 + k) * n + i] = un & valid;
-            m32[((size_t)b * 2 * W32 + W32 + k) * n + i] = dn & valid;
+            m32[((size_t)b * 2 * W32 + k) * n + i] = (un | nanbits) & valid;
+            m32[((size_t)b * 2 * W32 + W32 + k) * n + i] = (dn | nanbits) & valid;
         }
     }
 }
