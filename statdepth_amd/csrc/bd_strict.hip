@@ -237,10 +237,13 @@ __global__ __launch_bounds__(ST_THREADS) void strict_gather_rank_targets_kernel(
     const i64 tg = targets ? targets[q0 + b] : q0 + b;
     const i64 Tp = ((T + 31) / 32) * 32;
     bool isn = false;
-    for (i64 t = threadIdx.x; t < Tp; t += ST_THREADS) {
-        const u32 w = t < T ? R[t * n + tg] : 0u;
-        isn |= w == ST_RANK_NAN;
-        Rt[b * Tp + t] = w & 0xFFFFu;
+    // packed for the mask kernel: word k's timepoints j and j + 16 share Rt[b][16 k + j] (low / high half)
+    for (i64 e = threadIdx.x; e < Tp / 2; e += ST_THREADS) {
+        const i64 t = (e / 16) * 32 + (e % 16);
+        const u32 w0 = t < T ? R[t * n + tg] : 0u;
+        const u32 w1 = t + 16 < T ? R[(t + 16) * n + tg] : 0u;
+        isn |= w0 == ST_RANK_NAN || w1 == ST_RANK_NAN;
+        Rt[b * (Tp / 2) + e] = (w0 & 0xFFFFu) | ((w1 & 0xFFFFu) << 16);
     }
     if (__syncthreads_or(isn) && threadIdx.x == 0) xnan[b] = 1;
 }
@@ -254,31 +257,45 @@ __global__ __launch_bounds__(ST_THREADS) void strict_masks_rank_kernel(
     const i64 t0 = (i64)k * 32;
     const int tl = (int)(T - t0 < 32 ? T - t0 : 32);
     const u32 valid = tl == 32 ? 0xFFFFFFFFu : ((1u << tl) - 1u);
-    u32 x[32];
+    // two timepoints per register: x2 = rank at t0 + j | rank at t0 + j + 16 << 16 (ranks < 2^15: bit 15 of each half is
+    // free), kept as x2 + H and x2 - H (H = 0x80008000) for the two subtractions below
+    u32 xh[16], xm[16];
     u32 nanbits = 0;
 #pragma unroll
-    for (int t = 0; t < 32; ++t) {
-        const u32 w = (i < n && t < tl) ? R[(t0 + t) * n + i] : 0u;
-        const bool isn = w == ST_RANK_NAN;
-        nanbits |= isn ? (1u << t) : 0u;
-        x[t] = isn ? 0u : (w & 0xFFFFu);
+    for (int j = 0; j < 16; ++j) {
+        const u32 w0 = (i < n && j < tl) ? R[(t0 + j) * n + i] : 0u;
+        const u32 w1 = (i < n && j + 16 < tl) ? R[(t0 + j + 16) * n + i] : 0u;
+        const bool n0 = w0 == ST_RANK_NAN, n1 = w1 == ST_RANK_NAN;
+        nanbits |= (n0 ? (1u << j) : 0u) | (n1 ? (1u << (j + 16)) : 0u);
+        const u32 x2 = (n0 ? 0u : (w0 & 0xFFFFu)) | ((n1 ? 0u : (w1 & 0xFFFFu)) << 16);
+        xh[j] = x2 + 0x80008000u;
+        xm[j] = x2 - 0x80008000u;
     }
     const i64 bend = ((i64)blockIdx.z + 1) * ST_TG < nb ? ((i64)blockIdx.z + 1) * ST_TG : nb;
     for (i64 b = (i64)blockIdx.z * ST_TG; b < bend; ++b) {
-        const u32 *__restrict__ xq = Rt + (b * W32 + k) * 32;      // wave-uniform, contiguous: wide scalar loads
-        // ranks are < 2^16, so the sign bit of a difference IS the comparison; v_alignbit shifts it in from the right:
-        // two full-rate instructions per (timepoint, direction), no condition codes.  t runs down so that t = 0 ends
-        // in bit 0 (the 32 shifts push the initial value out).
-        u32 un = 0, dn = 0;
+        const u32 *__restrict__ xq = Rt + (b * W32 + k) * 16;      // wave-uniform, contiguous: one wide scalar load
+        // Both halves at once with plain 32-bit subtractions: each half of (q2 + H) - x2 = q2 - (x2 - H) is
+        // q + 0x8000 - x > 0 (no borrow between the halves) and its bit 15 says x <= q; likewise (x2 + H) - q2 for
+        // x >= q.  The accumulators rotate right by one per step and take the two bits at 15 and 31 (v_bfi): after 16
+        // steps timepoint j sits in bit j and j + 16 in bit 16 + j.  1.5 full-rate instructions per (timepoint,
+        // direction); the accumulated sense is inverted (NOT above / NOT below).
+        const u32 H = 0x80008000u;
+        typedef u32 u32x16 __attribute__((ext_vector_type(16)));
+        const u32x16 qv = *reinterpret_cast<const u32x16 *>(xq);        // s_load_dwordx16
+        u32 na = 0, nb_ = 0;
 #pragma unroll
-        for (int t = 31; t >= 0; --t) {
-            const u32 q = xq[t];
-            un = __builtin_amdgcn_alignbit(un, q - x[t], 31);           // (un << 1) | (x > q)
-            dn = __builtin_amdgcn_alignbit(dn, x[t] - q, 31);           // (dn << 1) | (x < q)
+        for (int j = 0; j < 16; ++j) {
+            const u32 q2 = qv[j];
+            const u32 d1 = q2 - xm[j];                                  // (q + 0x8000) - x per half; bit 15 / 31: x <= q
+            const u32 d2 = xh[j] - q2;                                  // (x + 0x8000) - q per half; bit 15 / 31: x >= q
+            // rotate right by one, then take bits 15 and 31 from the difference (the compiler's own rendering of this
+            // costs a third instruction)
+            asm("v_alignbit_b32 %0, %0, %0, 1\n\tv_bfi_b32 %0, %2, %1, %0" : "+v"(na) : "v"(d1), "s"(H));
+            asm("v_alignbit_b32 %0, %0, %0, 1\n\tv_bfi_b32 %0, %2, %1, %0" : "+v"(nb_) : "v"(d2), "s"(H));
         }
         if (i < n) {
-            m32[((size_t)b * 2 * W32 + k) * n + i] = (un | nanbits) & valid;
-            m32[((size_t)b * 2 * W32 + W32 + k) * n + i] = (dn | nanbits) & valid;
+            m32[((size_t)b * 2 * W32 + k) * n + i] = (~na | nanbits) & valid;
+            m32[((size_t)b * 2 * W32 + W32 + k) * n + i] = (~nb_ | nanbits) & valid;
         }
     }
 }
