@@ -37,7 +37,7 @@ static inline i64 strict_table_slots(i64 n) {
 static inline bool strict_match_applies(i64 T, i64 n, int J) { return J == 2 && (T + 31) / 32 <= 65535 && n <= ST_MATCH_MAXN; }
 
 static i64 strict_batch(i64 T, i64 n, i64 m) {
-    size_t per = (size_t)n * 2 * strict_words(T) * 8 + (size_t)strict_table_slots(n) * 16 + 20 + (size_t)((n + 63) / 64) * 8 + (size_t)((T + 31) / 32) * 256 + (size_t)n * 8;
+    size_t per = (size_t)n * 2 * strict_words(T) * 8 + (size_t)strict_table_slots(n) * 16 + 20 + (size_t)((n + 63) / 64) * 8 + (size_t)((T + 31) / 32) * 256 + (size_t)n * 9;
     i64 b = (i64)(((size_t)2048 << 20) / (per ? per : 1));   // up to 2 GiB of masks and tables per batch
     if (b < 1) b = 1;
     if (b > m) b = m;
@@ -51,7 +51,7 @@ size_t bd_strict_workspace_bytes(i64 T, i64 n, i64 m, int J) {
     return align_up((size_t)b * n * 2 * strict_words(T) * 8, 256) + align_up((size_t)b * 4, 256) +
            align_up((size_t)b * (strict_table_slots(n) * 16 + 16 + ((n + 63) / 64) * 8), 256) +
            align_up((size_t)((T + 31) / 32) * 4, 256) + align_up((size_t)b * ((T + 31) / 32) * 256, 256) +
-           align_up((size_t)b * n * 8, 256) + align_up((size_t)(b + 1) * 4, 256) +
+           align_up((size_t)b * n * 8, 256) + align_up((size_t)b * n, 256) + align_up((size_t)(b + 1) * 4, 256) +
            (n <= ST_RANK_MAXN ? align_up((size_t)T * n * 4, 256) + align_up((size_t)T * 4, 256) : 0) + 2560;
 }
 
@@ -173,6 +173,30 @@ constexpr int ST_W32 = 32;                  // mask words per kind kept in regis
 constexpr int ST_TG = 32;                   // targets per block of the mask kernel
 constexpr int ST_SUB = 64;
 
+// How the mask kernels store a (target, curve, word) pair.  FULL: UN and DN words (the pair kernel's input).  With
+// matching on, the first pass over a batch stores UN only and notes in dflag[b][i] whether the curve is dirty for the
+// target (tie or NaN at a timepoint that counts: the only thing the matching needs DN for); DN words -- half of the
+// largest traffic of the strict path -- are then written by a second pass over the targets that have dirty curves
+// (dlist / *dcount, appended by the matching), which continuous data never runs.
+struct StrictMaskOut {
+    u32 *m32;
+    unsigned char *dflag;      // null: FULL
+    const u32 *cmask;          // with dflag: timepoints that do not count
+    const u32 *dlist;          // null: every target of the batch, else the listed ones
+    const u32 *dcount;
+};
+__device__ __forceinline__ void strict_store_masks(const StrictMaskOut &o, i64 b, int k, int W32, i64 n, i64 i, u32 un, u32 dn,
+                                                   u32 valid) {
+    if (i >= n) return;
+    o.m32[((size_t)b * 2 * W32 + k) * n + i] = un;
+    if (!o.dflag) {
+        o.m32[((size_t)b * 2 * W32 + W32 + k) * n + i] = dn;
+    } else {
+        const u32 v = valid & ~o.cmask[k];
+        if ((((un ^ dn) & v) != v) || (un & dn)) o.dflag[(size_t)b * n + i] = 1;      // rare: continuous data never stores
+    }
+}
+
 // The batch's target curves, gathered curve-major and padded to whole words: Yt[b][t], t < Tp = 32 W32 (zero beyond T).
 // The mask kernel then fetches a target's 32 values of a word with a few wide scalar loads instead of 32 strided ones;
 // a NaN anywhere in the target is noted here.  grid = nb
@@ -193,7 +217,11 @@ __global__ __launch_bounds__(ST_THREADS) void strict_gather_targets_kernel(
 
 // grid = (ceil(n / 256), W32, ceil(nb / ST_TG))
 __global__ __launch_bounds__(ST_THREADS) void strict_masks2_kernel(
-    const double *__restrict__ Y, const double *__restrict__ Yt, i64 T, i64 n, i64 nb, u32 *__restrict__ m32) {
+    const double *__restrict__ Y, const double *__restrict__ Yt, i64 T, i64 n, i64 nb, StrictMaskOut o) {
+    const i64 cnt = o.dlist ? (i64)*o.dcount : nb;
+    const i64 z0 = (i64)blockIdx.z * ST_TG;
+    if (z0 >= cnt) return;
+    const i64 zend = z0 + ST_TG < cnt ? z0 + ST_TG : cnt;
     const i64 i = (i64)blockIdx.x * ST_THREADS + threadIdx.x;
     const int k = blockIdx.y;
     const int W32 = (int)((T + 31) / 32);
@@ -207,8 +235,8 @@ __global__ __launch_bounds__(ST_THREADS) void strict_masks2_kernel(
         x[t] = (i < n && t < tl) ? Y[(t0 + t) * n + i] : 0.0;
         nanbits |= (x[t] != x[t]) ? (1u << t) : 0u;
     }
-    const i64 bend = ((i64)blockIdx.z + 1) * ST_TG < nb ? ((i64)blockIdx.z + 1) * ST_TG : nb;
-    for (i64 b = (i64)blockIdx.z * ST_TG; b < bend; ++b) {
+    for (i64 z = z0; z < zend; ++z) {
+        const i64 b = o.dlist ? (i64)o.dlist[z] : z;
         const double *__restrict__ xq = Yt + (b * W32 + k) * 32;    // wave-uniform, contiguous: wide scalar loads
         u32 un = nanbits, dn = nanbits;
 #pragma unroll
@@ -217,10 +245,7 @@ __global__ __launch_bounds__(ST_THREADS) void strict_masks2_kernel(
             un |= (x[t] > q) ? (1u << t) : 0u;
             dn |= (x[t] < q) ? (1u << t) : 0u;
         }
-        if (i < n) {
-            m32[((size_t)b * 2 * W32 + k) * n + i] = un & valid;
-            m32[((size_t)b * 2 * W32 + W32 + k) * n + i] = dn & valid;
-        }
+        strict_store_masks(o, b, k, W32, n, i, un & valid, dn & valid, valid);
     }
 }
 
@@ -250,7 +275,11 @@ __global__ __launch_bounds__(ST_THREADS) void strict_gather_rank_targets_kernel(
 
 // grid = (ceil(n / 256), W32, ceil(nb / ST_TG))
 __global__ __launch_bounds__(ST_THREADS) void strict_masks_rank_kernel(
-    const u32 *__restrict__ R, const u32 *__restrict__ Rt, i64 T, i64 n, i64 nb, u32 *__restrict__ m32) {
+    const u32 *__restrict__ R, const u32 *__restrict__ Rt, i64 T, i64 n, i64 nb, StrictMaskOut o) {
+    const i64 cnt = o.dlist ? (i64)*o.dcount : nb;
+    const i64 z0 = (i64)blockIdx.z * ST_TG;
+    if (z0 >= cnt) return;
+    const i64 zend = z0 + ST_TG < cnt ? z0 + ST_TG : cnt;
     const i64 i = (i64)blockIdx.x * ST_THREADS + threadIdx.x;
     const int k = blockIdx.y;
     const int W32 = (int)((T + 31) / 32);
@@ -271,8 +300,8 @@ __global__ __launch_bounds__(ST_THREADS) void strict_masks_rank_kernel(
         xh[j] = x2 + 0x80008000u;
         xm[j] = x2 - 0x80008000u;
     }
-    const i64 bend = ((i64)blockIdx.z + 1) * ST_TG < nb ? ((i64)blockIdx.z + 1) * ST_TG : nb;
-    for (i64 b = (i64)blockIdx.z * ST_TG; b < bend; ++b) {
+    for (i64 z = z0; z < zend; ++z) {
+        const i64 b = o.dlist ? (i64)o.dlist[z] : z;
         const u32 *__restrict__ xq = Rt + (b * W32 + k) * 16;      // wave-uniform, contiguous: one wide scalar load
         // Both halves at once with plain 32-bit subtractions: each half of (q2 + H) - x2 = q2 - (x2 - H) is
         // q + 0x8000 - x > 0 (no borrow between the halves) and its bit 15 says x <= q; likewise (x2 + H) - q2 for
@@ -293,14 +322,11 @@ __global__ __launch_bounds__(ST_THREADS) void strict_masks_rank_kernel(
             asm("v_alignbit_b32 %0, %0, %0, 1\n\tv_bfi_b32 %0, %2, %1, %0" : "+v"(na) : "v"(d1), "s"(H));
             asm("v_alignbit_b32 %0, %0, %0, 1\n\tv_bfi_b32 %0, %2, %1, %0" : "+v"(nb_) : "v"(d2), "s"(H));
         }
-        if (i < n) {
-            m32[((size_t)b * 2 * W32 + k) * n + i] = (~na | nanbits) & valid;
-            m32[((size_t)b * 2 * W32 + W32 + k) * n + i] = (~nb_ | nanbits) & valid;
-        }
+        strict_store_masks(o, b, k, W32, n, i, (~na | nanbits) & valid, (~nb_ | nanbits) & valid, valid);
     }
 }
 
-// What the complement matching below needs per (target, curve), read off the masks once:
+// What the complement matching below needs per (target, curve), read off the UN masks once:
 //   HF[b][i] = payload (60 bits) << 4 | exact << 3 | side << 2 | canonical mask non-empty << 1 | clean
 // payload: the canonical mask itself when it has one non-zero word (exact = 1: word index << 32 | word), else 60 hash bits
 // (canonical form, side, clean: see the matching section; cmask marks the timepoints that do not count).
@@ -328,7 +354,7 @@ __device__ __forceinline__ StrictFirst strict_first_counting(const u32 *__restri
 
 __global__ __launch_bounds__(ST_THREADS) void strict_hash_kernel(const u32 *__restrict__ m32, i64 T, i64 n,
                                                                 const u32 *__restrict__ xnan, const u32 *__restrict__ cmask,
-                                                                u64 *__restrict__ HF) {
+                                                                const unsigned char *__restrict__ dflag, u64 *__restrict__ HF) {
     const i64 b = blockIdx.y;
     if (xnan[b]) return;
     const i64 a = (i64)blockIdx.x * ST_THREADS + threadIdx.x;
@@ -337,7 +363,8 @@ __global__ __launch_bounds__(ST_THREADS) void strict_hash_kernel(const u32 *__re
     const u32 lastvalid = (T & 31) ? ((1u << (T & 31)) - 1u) : 0xFFFFFFFFu;
     const u32 *mb = m32 + (size_t)b * 2 * W32 * n;
     const StrictFirst fc = strict_first_counting(cmask, W32, lastvalid);
-    bool clean = fc.vf != 0;                                  // every row constant: nothing is clean (pair kernel)
+    // dirty (tie / NaN where it counts): noted by the mask kernel; every row constant: nothing is clean (pair kernel)
+    const bool clean = fc.vf != 0 && dflag[(size_t)b * n + a] == 0;
     u32 side = 0, flip = 0;
     if (fc.vf) {
         side = (mb[(size_t)fc.wf * n + a] >> (__ffs((int)fc.vf) - 1)) & 1u;
@@ -345,20 +372,18 @@ __global__ __launch_bounds__(ST_THREADS) void strict_hash_kernel(const u32 *__re
     }
     u64 h = 0x9E3779B97F4A7C15ull;
     u32 one = 0, onek = 0, nz = 0;                            // the only non-zero canonical word, its index, how many there are
-    for (int w0 = 0; w0 < W32; w0 += 8) {
-        u32 un[8], dn[8];
+    for (int w0 = 0; w0 < W32; w0 += 16) {
+        u32 un[16];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {                         // sixteen loads in flight
+        for (int j = 0; j < 16; ++j) {                        // sixteen loads in flight
             const int w = w0 + j < W32 ? w0 + j : W32 - 1;
             un[j] = mb[(size_t)w * n + a];
-            dn[j] = mb[(size_t)(W32 + w) * n + a];
         }
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
+        for (int j = 0; j < 16; ++j) {
             const int w = w0 + j;
             if (w < W32) {
                 const u32 v = (w == W32 - 1 ? lastvalid : 0xFFFFFFFFu) & ~cmask[w];
-                clean &= ((un[j] ^ dn[j]) & v) == v && ((un[j] & dn[j]) == 0);   // above or below, not both (NaN), wherever it counts
                 const u32 cw = (un[j] ^ flip) & v;
                 if (cw) { one = cw; onek = (u32)w; ++nz; }
                 h = strict_mix(h, cw);
@@ -820,8 +845,9 @@ int launch_bd_strict(const double *Y, i64 T, i64 n, const i64 *targets, i64 m, i
     u32 *cmask = (u32 *)cv.take((size_t)((T + 31) / 32) * 4);
     double *Yt = (double *)cv.take((size_t)B * ((T + 31) / 32) * 256);
     u64 *HF = (u64 *)cv.take((size_t)B * n * 8);                                    // hash + flags per (target, curve)
+    unsigned char *dflag = (unsigned char *)cv.take((size_t)B * n);                 // dirty (target, curve) pairs
     u32 *dlist = (u32 *)cv.take((size_t)(B + 1) * 4);                               // dirty targets of the batch | their number
-    if (!masks || !xnan || !tab || !cmask || !Yt || !HF || !dlist)
+    if (!masks || !xnan || !tab || !cmask || !Yt || !HF || !dflag || !dlist)
         return fail(SD_ERR_WORKSPACE, "strict-depth workspace too small");
     u32 *dcount = dlist + B;
     // cross-check builds, SD_STRICT_FP64_MASKS = 1: masks from the fp64 values at any n
@@ -867,18 +893,21 @@ int launch_bd_strict(const double *Y, i64 T, i64 n, const i64 *targets, i64 m, i
         if (gen2 || match) {
             // second generation: 32-bit words, word-major image (fits the same workspace: 2 W32 n u32 <= 2 W n u64)
             dim3 g1b((unsigned)((n + ST_THREADS - 1) / ST_THREADS), (unsigned)W32, (unsigned)((nb + ST_TG - 1) / ST_TG));
+            // with matching, the first pass stores UN words and dirty flags only (see StrictMaskOut)
+            StrictMaskOut mo{(u32 *)masks, match ? dflag : nullptr, cmask, nullptr, nullptr};
+            if (match) SD_HIP(hipMemsetAsync(dflag, 0, (size_t)nb * n, s));
             if (rankmasks) {
                 hipLaunchKernelGGL(strict_gather_rank_targets_kernel, dim3((unsigned)nb), dim3(ST_THREADS), 0, s, (const u32 *)R, T, n,
                                    targets, q0, (u32 *)Yt, xnan);
-                hipLaunchKernelGGL(strict_masks_rank_kernel, g1b, dim3(ST_THREADS), 0, s, (const u32 *)R, (const u32 *)Yt, T, n, nb,
-                                   (u32 *)masks);
+                hipLaunchKernelGGL(strict_masks_rank_kernel, g1b, dim3(ST_THREADS), 0, s, (const u32 *)R, (const u32 *)Yt, T, n, nb, mo);
             } else {
                 hipLaunchKernelGGL(strict_gather_targets_kernel, dim3((unsigned)nb), dim3(ST_THREADS), 0, s, Y, T, n, targets, q0, Yt,
                                    xnan);
-                hipLaunchKernelGGL(strict_masks2_kernel, g1b, dim3(ST_THREADS), 0, s, Y, (const double *)Yt, T, n, nb, (u32 *)masks);
+                hipLaunchKernelGGL(strict_masks2_kernel, g1b, dim3(ST_THREADS), 0, s, Y, (const double *)Yt, T, n, nb, mo);
             }
             if (match) {
-                hipLaunchKernelGGL(strict_hash_kernel, g1, dim3(ST_THREADS), 0, s, (const u32 *)masks, T, n, xnan, (const u32 *)cmask, HF);
+                hipLaunchKernelGGL(strict_hash_kernel, g1, dim3(ST_THREADS), 0, s, (const u32 *)masks, T, n, xnan, (const u32 *)cmask,
+                                   (const unsigned char *)dflag, HF);
                 if (lds_match) {
                     SD_HIP(hipMemsetAsync(dirty, 0, (size_t)B * 16, s));
                     SD_HIP(hipMemsetAsync(dcount, 0, 4, s));
@@ -898,6 +927,15 @@ int launch_bd_strict(const double *Y, i64 T, i64 n, const i64 *targets, i64 m, i
                                        0, s, (const u32 *)cnt, slots, q0, xnan, (const u32 *)dirty, dlist, dcount, gen2 ? 0 : 1, out, jcols);
                 }
                 gate = dirty;
+                if (gen2) {
+                    // second pass: full masks (UN and DN) for the targets on the pair kernel's work list
+                    StrictMaskOut mf{(u32 *)masks, nullptr, cmask, dlist, dcount};
+                    if (rankmasks)
+                        hipLaunchKernelGGL(strict_masks_rank_kernel, g1b, dim3(ST_THREADS), 0, s, (const u32 *)R, (const u32 *)Yt, T, n, nb,
+                                           mf);
+                    else
+                        hipLaunchKernelGGL(strict_masks2_kernel, g1b, dim3(ST_THREADS), 0, s, Y, (const double *)Yt, T, n, nb, mf);
+                }
             }
             if (gen2) {
                 if (gate) {
