@@ -300,17 +300,20 @@ __global__ __launch_bounds__(ST_THREADS) void strict_masks_rank_kernel(
         xh[j] = x2 + 0x80008000u;
         xm[j] = x2 - 0x80008000u;
     }
+    // Both halves at once with plain 32-bit subtractions: each half of (q2 + H) - x2 = q2 - (x2 - H) is
+    // q + 0x8000 - x > 0 (no borrow between the halves) and its bit 15 says x <= q; likewise (x2 + H) - q2 for
+    // x >= q.  The accumulators rotate right by one per step and take the two bits at 15 and 31 (v_bfi): after 16
+    // steps timepoint j sits in bit j and j + 16 in bit 16 + j.  1.5 full-rate instructions per (timepoint,
+    // direction); the accumulated sense is inverted (NOT above / NOT below).
+    // The next target's 16 rank pairs are fetched (one s_load_dwordx16) while this one's are used: the kernel was
+    // waiting on that scalar load for half of its cycles (SQ_WAIT_INST_ANY 0.55 of the wave cycles).
+    typedef u32 u32x16 __attribute__((ext_vector_type(16)));
+    const u32 H = 0x80008000u;
+    i64 b = o.dlist ? (i64)o.dlist[z0] : z0;
+    u32x16 qv = *reinterpret_cast<const u32x16 *>(Rt + (b * W32 + k) * 16);
     for (i64 z = z0; z < zend; ++z) {
-        const i64 b = o.dlist ? (i64)o.dlist[z] : z;
-        const u32 *__restrict__ xq = Rt + (b * W32 + k) * 16;      // wave-uniform, contiguous: one wide scalar load
-        // Both halves at once with plain 32-bit subtractions: each half of (q2 + H) - x2 = q2 - (x2 - H) is
-        // q + 0x8000 - x > 0 (no borrow between the halves) and its bit 15 says x <= q; likewise (x2 + H) - q2 for
-        // x >= q.  The accumulators rotate right by one per step and take the two bits at 15 and 31 (v_bfi): after 16
-        // steps timepoint j sits in bit j and j + 16 in bit 16 + j.  1.5 full-rate instructions per (timepoint,
-        // direction); the accumulated sense is inverted (NOT above / NOT below).
-        const u32 H = 0x80008000u;
-        typedef u32 u32x16 __attribute__((ext_vector_type(16)));
-        const u32x16 qv = *reinterpret_cast<const u32x16 *>(xq);        // s_load_dwordx16
+        const i64 bn = z + 1 < zend ? (o.dlist ? (i64)o.dlist[z + 1] : z + 1) : b;
+        const u32x16 qn = *reinterpret_cast<const u32x16 *>(Rt + (bn * W32 + k) * 16);
         u32 na = 0, nb_ = 0;
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
@@ -323,6 +326,8 @@ __global__ __launch_bounds__(ST_THREADS) void strict_masks_rank_kernel(
             asm("v_alignbit_b32 %0, %0, %0, 1\n\tv_bfi_b32 %0, %2, %1, %0" : "+v"(nb_) : "v"(d2), "s"(H));
         }
         strict_store_masks(o, b, k, W32, n, i, (~na | nanbits) & valid, (~nb_ | nanbits) & valid, valid);
+        qv = qn;
+        b = bn;
     }
 }
 
