@@ -130,6 +130,16 @@ size_t sd_mbd_external_workspace_bytes(int64_t T, int64_t n, int64_t m, int J);
 int sd_mbd_subset_counts(const double *X, int64_t T, int64_t n, const int32_t *members, int64_t nb, int bs,
                          const int32_t *target, int J, int64_t *out, void *stream);
 
+/* The same estimator with the reference's default relax=False (`c // T`, _containment.py:80), J = 2: the number of pairs
+ * of the block's OTHER members whose band contains the target at EVERY timepoint, for nb (subset, target) pairs in one
+ * launch (one workgroup per pair, the block's masks in LDS).  Arguments as sd_mbd_subset_counts; out: int64[nb].
+ * Host: depth = out / C(block size, 2).  Blocks that do not fit the LDS (sd_bd_strict_subset_supported == 0:
+ * bs * (2 * ceil(T/32) + 2) * 4 bytes > ~158 KB) are refused with SD_ERR_UNSUPPORTED: evaluate those through
+ * sd_bd_strict_counts on the block's columns. */
+int sd_bd_strict_subset_counts(const double *X, int64_t T, int64_t n, const int32_t *members, int64_t nb, int bs,
+                               const int32_t *target, int64_t *out, void *stream);
+int sd_bd_strict_subset_supported(int64_t T, int bs);
+
 /* Finest-granularity form of K1 (tests, diagnostics): AB[(q*T + t)*2 + {0,1}] =
  * (#curves strictly above, #strictly below) target q at t, as uint32. */
 int sd_above_below(const double *X, int64_t T, int64_t n, int64_t st, int64_t sn,

@@ -362,6 +362,18 @@ int sd_bd_strict_j_counts(const double *X, int64_t T, int64_t n, int64_t st, int
     return launch_bd_strict(Y, T, n, targets, m, J, (u64 *)out, sws, need, s);
 }
 
+int sd_bd_strict_subset_counts(const double *X, int64_t T, int64_t n, const int32_t *members, int64_t nb, int bs,
+                               const int32_t *target, int64_t *out, void *stream) {
+    if (!X || !members || !target || !out) return fail(SD_ERR_INVALID, "null pointer");
+    if (T <= 0 || n <= 0 || nb < 0 || bs <= 0) return fail(SD_ERR_INVALID, "bad shape");
+    int rc = check_count_range(1, bs, 2);
+    if (rc) return rc;
+    if (nb == 0) return SD_OK;
+    return launch_bd_strict_subsets(X, T, n, members, nb, bs, target, (u64 *)out, (hipStream_t)stream);
+}
+
+int sd_bd_strict_subset_supported(int64_t T, int bs) { return T > 0 && bs > 0 && bd_strict_subsets_supported(T, bs) ? 1 : 0; }
+
 int sd_bd_strict_counts(const double *X, int64_t T, int64_t n, int64_t st, int64_t sn,
                         const int64_t *targets, int64_t m,
                         int64_t *out, void *ws, size_t ws_bytes, void *stream) {

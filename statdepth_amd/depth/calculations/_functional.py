@@ -188,7 +188,9 @@ def _samplefunctionaldepth(data: List[pd.DataFrame], K: int, to_compute: Union[l
     if cdef == 'r2_enum':
         raise NotImplementedError
 
-    batched = (cdef == 'r2' and relax)
+    # every (target, block) pair in one launch: relax=True always; the reference's default relax=False for J = 2 when a
+    # block's masks fit the LDS (they do unless n / K runs into the thousands)
+    batched = cdef == 'r2' and (relax or (J == 2 and engine.bd_strict_subset_supported(df.shape[0], ss + 1)))
     blocks, block_targets = [], []           # column positions (in data[0]) of every block, in draw order
     full = data[0]
     for col in orig.columns:
@@ -220,8 +222,12 @@ def _samplefunctionaldepth(data: List[pd.DataFrame], K: int, to_compute: Union[l
             mem[i, :len(b)] = b
         X = full.to_numpy(dtype=np.float64)
         T = X.shape[0]
-        counts = engine.mbd_subset_counts(X, mem, np.asarray(block_targets, dtype=np.int32), J=J,
-                                          device=device).astype(np.float64) / T
+        if relax:
+            counts = engine.mbd_subset_counts(X, mem, np.asarray(block_targets, dtype=np.int32), J=J,
+                                              device=device).astype(np.float64) / T
+        else:
+            counts = engine.bd_strict_subset_counts(X, mem, np.asarray(block_targets, dtype=np.int32),
+                                                    device=device).astype(np.float64)[:, None]
         sizes = np.array([len(b) for b in blocks], dtype=np.float64)
         depth = np.zeros(len(blocks))
         for j in range(2, J + 1):

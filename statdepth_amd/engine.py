@@ -200,6 +200,35 @@ def mbd_subset_counts(X, members, targets, J=2, device=None):
     return out.cpu().numpy()
 
 
+def bd_strict_subset_supported(T, bs):
+    """Does a block of `bs` curves x T timepoints fit sd_bd_strict_subset_counts (masks in LDS)?"""
+    return bool(_native.require_device().sd_bd_strict_subset_supported(int(T), int(bs)))
+
+
+def bd_strict_subset_counts(X, members, targets, device=None):
+    """int64[nb]: pairs of members[k]'s other curves (-1 padded) containing targets[k] at every t (sd_bd_strict_subset_counts)."""
+    t = torch()
+    lib = _native.require_device()
+    dev = _device(device)
+    Xd = X if (isinstance(X, t.Tensor) and X.is_cuda) else t.from_numpy(
+        np.ascontiguousarray(np.asarray(X, dtype=np.float64))).to(dev)
+    Xd = Xd.contiguous()
+    T, n = Xd.shape
+    mem = np.ascontiguousarray(np.asarray(members, dtype=np.int32))
+    tg = np.ascontiguousarray(np.asarray(targets, dtype=np.int32))
+    nb, bs = mem.shape
+    if len(tg) != nb:
+        raise ValueError("one target per block")
+    out = t.empty((nb,), dtype=t.int64, device=dev)
+    if nb == 0:
+        return out.cpu().numpy()
+    md, td = t.from_numpy(mem).to(dev), t.from_numpy(tg).to(dev)
+    with t.cuda.device(dev):
+        check(lib.sd_bd_strict_subset_counts(Xd.data_ptr(), T, n, md.data_ptr(), nb, bs, td.data_ptr(), out.data_ptr(),
+                                         _stream_ptr(dev)))
+    return out.cpu().numpy()
+
+
 def above_below(X, targets=None, device=None):
     """uint32 -> int64 [m, T, 2] strictly-above / strictly-below counts (sd_above_below)."""
     t = torch()

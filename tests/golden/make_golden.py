@@ -233,6 +233,24 @@ def build_cases():
         return out
     add(g9, "g9_ksampled")
 
+    def g9s(name):
+        # the same estimator with the reference's default relax=False: smooth, well separated curves so that whole
+        # blocks contain their target at every timepoint
+        R = _ref()
+        rng = np.random.default_rng(19)
+        t = np.linspace(0, 1, 25)
+        df = pd.DataFrame({f"c{i}": lvl + 0.15 * np.sin(2 * np.pi * (t + ph))
+                           for i, (lvl, ph) in enumerate(zip(rng.normal(size=24) * 2.0, rng.random(24)))})
+        np.random.seed(11)
+        t0 = time.time()
+        s = R["FunctionalDepth"]([df], K=3, relax=False)
+        out = {"name": name, "kind": "univariate_sampled", "ref": "_functional.py:153-186",
+               "call": {"K": 3, "J": 2, "relax": False, "np_random_seed": 11},
+               "input": _frame_json(df), "elapsed_s": time.time() - t0}
+        out.update(_series_json(s))
+        return out
+    add(g9s, "g9_ksampled_strict")
+
     # G3 / G4 multivariate simplex -------------------------------------------
     def multi_case(name, frames, ref, relax, to_compute=None):
         R = _ref()
