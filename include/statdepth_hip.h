@@ -121,6 +121,13 @@ int sd_mbd_external_counts(const double *X, int64_t T, int64_t n, const double *
  * structure (O(n + m) per timepoint, n <= 16384, J <= 3); with T*4 + 256 bytes it still works (pairwise, O(n m)). */
 size_t sd_mbd_external_workspace_bytes(int64_t T, int64_t n, int64_t m, int J);
 
+/* The same for the reference's default relax=False, J = 2: out[q] = number of pairs of X's curves whose band contains
+ * Q[:,q] at EVERY timepoint (`c // T`, _containment.py:80); depth of g within F u {g} = out / C(n+1, 2).  One launch for
+ * all of G (complement matching, see sd_bd_strict_counts). */
+size_t sd_bd_strict_external_workspace_bytes(int64_t T, int64_t n, int64_t m);
+int sd_bd_strict_external_counts(const double *X, int64_t T, int64_t n, const double *Q, int64_t m, int64_t *out, void *ws,
+                                 size_t ws_bytes, void *stream);
+
 /* Band totals of one target inside an explicit subset of the curves, for nb (subset, target) pairs in one launch:
  * the K-block sampled estimator (_samplefunctionaldepth, _functional.py:170-182) evaluates
  * _univariate_band_depth on n*K small blocks.  X time-major dense (st = n, sn = 1).

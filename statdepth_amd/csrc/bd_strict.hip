@@ -58,12 +58,13 @@ size_t bd_strict_workspace_bytes(i64 T, i64 n, i64 m, int J) {
 // masks[b][i][0..W) = UN, masks[b][i][W..2W) = DN
 __global__ __launch_bounds__(ST_THREADS) void strict_masks_kernel(
     const double *__restrict__ Y, i64 T, i64 n, const i64 *__restrict__ targets, i64 q0,
-    u64 *__restrict__ masks, u32 *__restrict__ xnan, const u32 *__restrict__ gate) {
+    u64 *__restrict__ masks, u32 *__restrict__ xnan, const u32 *__restrict__ gate, const double *__restrict__ Yt) {
     i64 i = (i64)blockIdx.x * ST_THREADS + threadIdx.x;
     i64 b = blockIdx.y;
     if (gate && gate[b * 4] == 0) return;      // target already counted by complement matching
     i64 q = q0 + b;
     i64 tg = targets ? targets[q] : q;
+    const double *tq = Yt ? Yt + b * (((T + 31) / 32) * 32) : nullptr;   // external targets: the gathered copy
     i64 W = (T + 63) / 64;
     u64 *mrow = masks + ((size_t)b * n + (i < n ? i : 0)) * 2 * W;
     bool anynan = false;
@@ -71,7 +72,7 @@ __global__ __launch_bounds__(ST_THREADS) void strict_masks_kernel(
         u64 un = 0, dn = 0;
         i64 tend = (w + 1) * 64 < T ? (w + 1) * 64 : T;
         for (i64 t = w * 64; t < tend; ++t) {
-            double xq = Y[t * n + tg];
+            double xq = tq ? tq[t] : Y[t * n + tg];
             double xi = i < n ? Y[t * n + i] : 0.0;
             anynan |= (xq != xq);
             u64 bit = (u64)1 << (t & 63);
@@ -201,14 +202,16 @@ __device__ __forceinline__ void strict_store_masks(const StrictMaskOut &o, i64 b
 // The mask kernel then fetches a target's 32 values of a word with a few wide scalar loads instead of 32 strided ones;
 // a NaN anywhere in the target is noted here.  grid = nb
 __global__ __launch_bounds__(ST_THREADS) void strict_gather_targets_kernel(
-    const double *__restrict__ Y, i64 T, i64 n, const i64 *__restrict__ targets, i64 q0, double *__restrict__ Yt,
-    u32 *__restrict__ xnan) {
+    const double *__restrict__ Y, i64 T, i64 n, const i64 *__restrict__ targets, i64 q0, const double *__restrict__ Q,
+    i64 mq, double *__restrict__ Yt, u32 *__restrict__ xnan) {
     const i64 b = blockIdx.x;
-    const i64 tg = targets ? targets[q0 + b] : q0 + b;
+    const i64 tg = Q ? q0 + b : (targets ? targets[q0 + b] : q0 + b);      // Q: external targets, T x mq time-major
+    const double *src = Q ? Q : Y;
+    const i64 ld = Q ? mq : n;
     const i64 Tp = ((T + 31) / 32) * 32;
     bool isn = false;
     for (i64 t = threadIdx.x; t < Tp; t += ST_THREADS) {
-        const double v = t < T ? Y[t * n + tg] : 0.0;
+        const double v = t < T ? src[t * ld + tg] : 0.0;
         isn |= v != v;
         Yt[b * Tp + t] = v;
     }
@@ -935,8 +938,31 @@ int launch_bd_strict_subsets(const double *Y, i64 T, i64 n, const int *members, 
     return SD_OK;
 }
 
+// Q != nullptr: the m targets are EXTERNAL curves (T x m, time-major), every curve of Y is an "other" (J = 2 only).
+static int launch_bd_strict_impl(const double *Y, i64 T, i64 n, const i64 *targets, const double *Q, i64 m, int J,
+                                 u64 *out, void *ws, size_t ws_bytes, hipStream_t s);
+
 int launch_bd_strict(const double *Y, i64 T, i64 n, const i64 *targets, i64 m, int J,
                      u64 *out, void *ws, size_t ws_bytes, hipStream_t s) {
+    return launch_bd_strict_impl(Y, T, n, targets, nullptr, m, J, out, ws, ws_bytes, s);
+}
+
+size_t bd_strict_external_workspace_bytes(i64 T, i64 n, i64 m) { return bd_strict_workspace_bytes(T, n, m, 2) + align_up((size_t)m * 8, 256); }
+
+int launch_bd_strict_external(const double *Y, i64 T, i64 n, const double *Q, i64 m, u64 *out, void *ws, size_t ws_bytes,
+                              hipStream_t s) {
+    // the kernels exclude "the target itself" from the others by its column index: -1 for every external target
+    Carver cv(ws, ws_bytes);
+    i64 *none = (i64 *)cv.take((size_t)m * 8);
+    const size_t need = bd_strict_workspace_bytes(T, n, m, 2);
+    void *sws = cv.take(need);
+    if (!none || !sws) return fail(SD_ERR_WORKSPACE, "strict-depth workspace too small (sd_bd_strict_external_workspace_bytes)");
+    SD_HIP(hipMemsetAsync(none, 0xFF, (size_t)m * 8, s));
+    return launch_bd_strict_impl(Y, T, n, none, Q, m, 2, out, sws, need, s);
+}
+
+static int launch_bd_strict_impl(const double *Y, i64 T, i64 n, const i64 *targets, const double *Q, i64 m, int J,
+                                 u64 *out, void *ws, size_t ws_bytes, hipStream_t s) {
     i64 W = strict_words(T);
     i64 B = strict_batch(T, n, m);
     Carver cv(ws, ws_bytes);
@@ -957,7 +983,7 @@ int launch_bd_strict(const double *Y, i64 T, i64 n, const i64 *targets, i64 m, i
         return fail(SD_ERR_WORKSPACE, "strict-depth workspace too small");
     u32 *dcount = dlist + B;
     // cross-check builds, SD_STRICT_FP64_MASKS = 1: masks from the fp64 values at any n
-    const bool rankmasks = n >= 2 && n <= ST_RANK_MAXN && J == 2 && xswitch("SD_STRICT_V1") != 1 && xswitch("SD_STRICT_FP64_MASKS") != 1;
+    const bool rankmasks = !Q && n >= 2 && n <= ST_RANK_MAXN && J == 2 && xswitch("SD_STRICT_V1") != 1 && xswitch("SD_STRICT_FP64_MASKS") != 1;
     u32 *R = nullptr, *rnan = nullptr;
     if (rankmasks) {
         R = (u32 *)cv.take((size_t)T * n * 4);
@@ -977,8 +1003,12 @@ int launch_bd_strict(const double *Y, i64 T, i64 n, const i64 *targets, i64 m, i
         for (int k = 0; k < J - 1; ++k) threads *= (double)n;
         if (threads > 4.0e9) return fail(SD_ERR_UNSUPPORTED, "strict J=%d enumeration too large for n=%lld", J, (long long)n);
     }
-    if (match)
-        hipLaunchKernelGGL(strict_const_rows_kernel, dim3((unsigned)((T + 31) / 32)), dim3(ST_THREADS), 0, s, Y, T, n, cmask);
+    if (match) {
+        if (Q)      // an external target does not share a value all of Y's curves share: every timepoint counts
+            SD_HIP(hipMemsetAsync(cmask, 0, (size_t)((T + 31) / 32) * 4, s));
+        else
+            hipLaunchKernelGGL(strict_const_rows_kernel, dim3((unsigned)((T + 31) / 32)), dim3(ST_THREADS), 0, s, Y, T, n, cmask);
+    }
     if (rankmasks) {
         // the image launcher takes at most 2048 rows per workgroup
         const i64 step = 2048 * 64;
@@ -1007,8 +1037,8 @@ int launch_bd_strict(const double *Y, i64 T, i64 n, const i64 *targets, i64 m, i
                                    targets, q0, (u32 *)Yt, xnan);
                 hipLaunchKernelGGL(strict_masks_rank_kernel, g1b, dim3(ST_THREADS), 0, s, (const u32 *)R, (const u32 *)Yt, T, n, nb, mo);
             } else {
-                hipLaunchKernelGGL(strict_gather_targets_kernel, dim3((unsigned)nb), dim3(ST_THREADS), 0, s, Y, T, n, targets, q0, Yt,
-                                   xnan);
+                hipLaunchKernelGGL(strict_gather_targets_kernel, dim3((unsigned)nb), dim3(ST_THREADS), 0, s, Y, T, n, targets, q0, Q, m,
+                                   Yt, xnan);
                 hipLaunchKernelGGL(strict_masks2_kernel, g1b, dim3(ST_THREADS), 0, s, Y, (const double *)Yt, T, n, nb, mo);
             }
             if (match) {
@@ -1062,7 +1092,11 @@ int launch_bd_strict(const double *Y, i64 T, i64 n, const i64 *targets, i64 m, i
             // targets that matching could not take (ties, NaN) go through the first generation below, which rebuilds
             // their masks in its own layout over the image just consumed (stream order)
         }
-        hipLaunchKernelGGL(strict_masks_kernel, g1, dim3(ST_THREADS), 0, s, Y, T, n, targets, q0, masks, xnan, gate);
+        if (Q && !(gen2 || match))      // external targets reach the first generation through their gathered copy
+            hipLaunchKernelGGL(strict_gather_targets_kernel, dim3((unsigned)nb), dim3(ST_THREADS), 0, s, Y, T, n, targets, q0, Q, m,
+                               Yt, xnan);
+        hipLaunchKernelGGL(strict_masks_kernel, g1, dim3(ST_THREADS), 0, s, Y, T, n, targets, q0, masks, xnan, gate,
+                           Q ? (const double *)Yt : (const double *)nullptr);
         if (W <= ST_WREG)
             hipLaunchKernelGGL((strict_pairs_kernel<true>), g2, dim3(ST_THREADS), 0, s, masks, T, n, targets, q0, xnan, gate, out, jcols);
         else

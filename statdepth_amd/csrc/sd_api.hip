@@ -362,6 +362,21 @@ int sd_bd_strict_j_counts(const double *X, int64_t T, int64_t n, int64_t st, int
     return launch_bd_strict(Y, T, n, targets, m, J, (u64 *)out, sws, need, s);
 }
 
+size_t sd_bd_strict_external_workspace_bytes(int64_t T, int64_t n, int64_t m) {
+    if (T <= 0 || n <= 0 || m <= 0) return 0;
+    return bd_strict_external_workspace_bytes(T, n, m) + 512;
+}
+
+int sd_bd_strict_external_counts(const double *X, int64_t T, int64_t n, const double *Q, int64_t m, int64_t *out, void *ws,
+                                 size_t ws_bytes, void *stream) {
+    if (!X || !Q || !out) return fail(SD_ERR_INVALID, "null pointer");
+    if (T <= 0 || n <= 0 || m < 0) return fail(SD_ERR_INVALID, "bad shape");
+    int rc = check_count_range(1, n + 1, 2);
+    if (rc) return rc;
+    if (m == 0) return SD_OK;
+    return launch_bd_strict_external(X, T, n, Q, m, (u64 *)out, ws, ws_bytes, (hipStream_t)stream);
+}
+
 int sd_bd_strict_subset_counts(const double *X, int64_t T, int64_t n, const int32_t *members, int64_t nb, int bs,
                                const int32_t *target, int64_t *out, void *stream) {
     if (!X || !members || !target || !out) return fail(SD_ERR_INVALID, "null pointer");

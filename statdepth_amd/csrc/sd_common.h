@@ -84,6 +84,9 @@ int launch_mbd_rank_big(const double *Y, i64 T, i64 n, const i64 *targets, i64 t
 size_t bd_strict_workspace_bytes(i64 T, i64 n, i64 m, int J);
 int launch_bd_strict(const double *Y, i64 T, i64 n, const i64 *targets, i64 m, int J,
                      u64 *out, void *ws, size_t ws_bytes, hipStream_t s);
+size_t bd_strict_external_workspace_bytes(i64 T, i64 n, i64 m);
+int launch_bd_strict_external(const double *Y, i64 T, i64 n, const double *Q, i64 m, u64 *out, void *ws, size_t ws_bytes,
+                              hipStream_t s);
 // K5 l1
 int launch_l1_depth(const double *P, i64 n, int d, const i64 *targets, i64 m, double *out, hipStream_t s);
 int launch_l1_external(const double *P, i64 n, int d, const double *Q, i64 m, double *out, hipStream_t s);

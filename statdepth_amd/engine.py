@@ -176,6 +176,28 @@ def mbd_external_counts(X, Q, J=2, device=None):
     return out.cpu().numpy()
 
 
+def bd_strict_external_counts(X, Q, device=None):
+    """int64[m]: pairs of X's n columns whose band contains column q of Q (T x m) at every t (sd_bd_strict_external_counts)."""
+    t = torch()
+    lib = _native.require_device()
+    dev = _device(device)
+    Xd = t.from_numpy(np.ascontiguousarray(np.asarray(X, dtype=np.float64))).to(dev)
+    Qd = t.from_numpy(np.ascontiguousarray(np.asarray(Q, dtype=np.float64))).to(dev)
+    T, n = Xd.shape
+    if Qd.dim() != 2 or Qd.shape[0] != T:
+        raise ValueError("Q must have the same number of timepoints as X")
+    m = Qd.shape[1]
+    out = t.empty((m,), dtype=t.int64, device=dev)
+    if m == 0:
+        return out.cpu().numpy()
+    wsb = int(lib.sd_bd_strict_external_workspace_bytes(T, n, m))
+    ws = t.empty(max(wsb, 8), dtype=t.uint8, device=dev)
+    with t.cuda.device(dev):
+        check(lib.sd_bd_strict_external_counts(Xd.data_ptr(), T, n, Qd.data_ptr(), m, out.data_ptr(), ws.data_ptr(), wsb,
+                                           _stream_ptr(dev)))
+    return out.cpu().numpy()
+
+
 def mbd_subset_counts(X, members, targets, J=2, device=None):
     """int64[nb, J-1]: band totals of targets[k] inside the curves members[k] (-1 padded) -- sd_mbd_subset_counts."""
     t = torch()

@@ -67,7 +67,8 @@ def _handle_errors(F, G, method='p1'):
 
 
 def _depths_of_external(F: pd.DataFrame, Gcols: pd.DataFrame, J: int, relax: bool) -> np.ndarray:
-    """Depth of every column g of `Gcols` inside F u {g}, one launch (built-in 'r2', relax=True).
+    """Depth of every column g of `Gcols` inside F u {g}, one launch (built-in 'r2'; relax=True, or the
+    reference's default relax=False with J = 2).
 
     The reference builds F with g appended (n_F + 1 columns) and divides by binom(n_F + 1, j)
     (_functional.py:229,253); bands come from the n_F curves of F (:235).
@@ -75,7 +76,10 @@ def _depths_of_external(F: pd.DataFrame, Gcols: pd.DataFrame, J: int, relax: boo
     Fx = F.to_numpy(dtype=np.float64)
     Gx = Gcols.to_numpy(dtype=np.float64)
     T, nF = Fx.shape
-    counts = engine.mbd_external_counts(Fx, Gx, J=J).astype(np.float64) / T
+    if relax:
+        counts = engine.mbd_external_counts(Fx, Gx, J=J).astype(np.float64) / T
+    else:
+        counts = engine.bd_strict_external_counts(Fx, Gx).astype(np.float64)[:, None]      # `c // T`: every timepoint
     depth = np.zeros(Gx.shape[1])
     for j in range(2, J + 1):
         depth += counts[:, j - 2] / binom(nF + 1, j)
@@ -113,7 +117,7 @@ def _functionalhomogeneity(F: List[pd.DataFrame], G: List[pd.DataFrame], K=None,
             Fd = Fd.drop('g_deepest', axis=1)
         G_deepest = G_depths.get_deepest_data(n=1)          # (:95)
         # every g is evaluated inside the intact F u {g} (n_F + 1 curves), batched or not: one semantics for both
-        batched = (K is None and containment == 'r2' and relax)
+        batched = K is None and containment == 'r2' and (relax or J == 2)
         if batched:
             deep = _depths_of_external(Fd, G_deepest, J, relax)
         else:
