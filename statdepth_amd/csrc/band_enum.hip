@@ -26,6 +26,8 @@
 
 namespace sd {
 
+int launch_rank_bucket_image(const double *Y, i64 n, i64 row0, i64 rows, u32 *AB, u32 *nnan, hipStream_t s);   // mbd_rank_bucket.hip
+
 template <int D>
 struct BECfg {
     static constexpr int pow3(int k) { return k == 0 ? 1 : 3 * pow3(k - 1); }
@@ -35,9 +37,11 @@ struct BECfg {
 };
 
 // grid = (T, QG): block (t, g) serves targets g, g + QG, ... at timepoint t.
-// AB[(a * R + r) * 2 + 1] = B of curve a in component row r = t * D + f (sd_above_below over the R = T * D rows).
+// AB[(a * R + r) * 2 + 1] = B of curve a in component row r = t * D + f (sd_above_below over the R = T * D rows: n >
+// 16 384), or ranks[r][a] & 0xFFFF = the same B from the bucket kernel's image mode (n <= 16 384: one pass of the
+// headline kernel instead of the O(n^2) pairwise one -- 12 of config 4's 81 ms).
 template <int D>
-__global__ __launch_bounds__(1024) void band_class_kernel(const u32 *__restrict__ AB, i64 n64, i64 T,
+__global__ __launch_bounds__(1024) void band_class_kernel(const u32 *__restrict__ AB, const u32 *__restrict__ ranks, i64 n64, i64 T,
                                                          const i64 *__restrict__ targets, i64 m, u64 *__restrict__ out) {
     using C = BECfg<D>;
     constexpr int NC = C::NC, NT = C::NT;
@@ -50,9 +54,16 @@ __global__ __launch_bounds__(1024) void band_class_kernel(const u32 *__restrict_
     const int t = threadIdx.x;
     const i64 tp = blockIdx.x;
     const i64 RR = T * D;
-    for (i64 idx = t; idx < (i64)n * D; idx += NT) {
-        const i64 a = idx / D, f = idx % D;
-        R[idx] = (unsigned short)AB[((a * RR) + tp * D + f) * 2 + 1];
+    if (ranks) {            // bucket kernel's image: ranks[row][curve] = B | A << 16, the curves of a row contiguous
+        for (i64 idx = t; idx < (i64)n * D; idx += NT) {
+            const i64 f = idx / n, a = idx % n;
+            R[a * D + f] = (unsigned short)(ranks[(tp * D + f) * n + a] & 0xFFFFu);
+        }
+    } else {
+        for (i64 idx = t; idx < (i64)n * D; idx += NT) {
+            const i64 a = idx / D, f = idx % D;
+            R[idx] = (unsigned short)AB[((a * RR) + tp * D + f) * 2 + 1];
+        }
     }
     __syncthreads();
     for (i64 qi = blockIdx.y; qi < m; qi += gridDim.y) {
@@ -141,7 +152,16 @@ int launch_multi_band(const double *P, i64 n, i64 T, int d, const i64 *targets, 
     if (!Y || !AB) return fail(SD_ERR_WORKSPACE, "workspace too small (sd_multi_band_workspace_bytes)");
     int rc;
     if ((rc = launch_to_time_major(P, R, n, 1, R, Y, s))) return rc;
-    if ((rc = launch_above_below(Y, R, n, nullptr, n, AB, s))) return rc;          // every curve's B in every component row
+    const bool image = n <= 16384;
+    if (image) {
+        // every curve's B in every component row: image mode of the bucket kernel (at most 2048 rows per workgroup and launch)
+        u32 *nn = AB + (size_t)R * n;                                               // NaN counts per row (unused: NaN-free input)
+        const i64 step = 2048 * 64;
+        for (i64 r0 = 0; r0 < R; r0 += step)
+            if ((rc = launch_rank_bucket_image(Y, n, r0, R - r0 < step ? R - r0 : step, AB + r0 * n, nn + r0, s))) return rc;
+    } else if ((rc = launch_above_below(Y, R, n, nullptr, n, AB, s))) {
+        return rc;
+    }
     SD_HIP(hipMemsetAsync(out, 0, sizeof(u64) * m, s));
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) {
@@ -158,7 +178,8 @@ int launch_multi_band(const double *P, i64 n, i64 T, int d, const i64 *targets, 
         auto kf = band_class_kernel<D_>;                                                                             \
         const size_t lds = BECfg<D_>::lds_bytes(n);                                                                  \
         SD_HIP(hipFuncSetAttribute((const void *)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));        \
-        hipLaunchKernelGGL(kf, grid, dim3(1024), lds, s, (const u32 *)AB, n, T, targets, m, out);                    \
+        hipLaunchKernelGGL(kf, grid, dim3(1024), lds, s, image ? (const u32 *)nullptr : (const u32 *)AB,          \
+                           image ? (const u32 *)AB : (const u32 *)nullptr, n, T, targets, m, out);                  \
     } break;
     switch (d) {
         BE_CASE(1) BE_CASE(2) BE_CASE(3) BE_CASE(4) BE_CASE(5) BE_CASE(6) BE_CASE(7) BE_CASE(8)
