@@ -303,6 +303,10 @@ __global__ __launch_bounds__(ST_THREADS) void strict_masks_rank_kernel(
         xh[j] = x2 + 0x80008000u;
         xm[j] = x2 - 0x80008000u;
     }
+    // First pass of a matching batch over a full word in which every timepoint counts: only UN is stored, and of DN
+    // only "is there a tie" is wanted -- a packed running minimum of x2 ^ q2 (a zero half = equal ranks = a tie)
+    // instead of the second subtract / rotate / insert: 2.5 instead of 3 instructions per timepoint.
+    const bool un_only = o.dflag != nullptr && tl == 32 && o.cmask[k] == 0;
     // Both halves at once with plain 32-bit subtractions: each half of (q2 + H) - x2 = q2 - (x2 - H) is
     // q + 0x8000 - x > 0 (no borrow between the halves) and its bit 15 says x <= q; likewise (x2 + H) - q2 for
     // x >= q.  The accumulators rotate right by one per step and take the two bits at 15 and 31 (v_bfi): after 16
@@ -318,17 +322,35 @@ __global__ __launch_bounds__(ST_THREADS) void strict_masks_rank_kernel(
         const i64 bn = z + 1 < zend ? (o.dlist ? (i64)o.dlist[z + 1] : z + 1) : b;
         const u32x16 qn = *reinterpret_cast<const u32x16 *>(Rt + (bn * W32 + k) * 16);
         u32 na = 0, nb_ = 0;
+        if (un_only) {                                                  // block-uniform
+            typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+            u16x2 mn = {0xFFFF, 0xFFFF};
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const u32 q2 = qv[j];
-            const u32 d1 = q2 - xm[j];                                  // (q + 0x8000) - x per half; bit 15 / 31: x <= q
-            const u32 d2 = xh[j] - q2;                                  // (x + 0x8000) - q per half; bit 15 / 31: x >= q
-            // rotate right by one, then take bits 15 and 31 from the difference (the compiler's own rendering of this
-            // costs a third instruction)
-            asm("v_alignbit_b32 %0, %0, %0, 1\n\tv_bfi_b32 %0, %2, %1, %0" : "+v"(na) : "v"(d1), "s"(H));
-            asm("v_alignbit_b32 %0, %0, %0, 1\n\tv_bfi_b32 %0, %2, %1, %0" : "+v"(nb_) : "v"(d2), "s"(H));
+            for (int j = 0; j < 16; ++j) {
+                const u32 q2 = qv[j];
+                const u32 d1 = q2 - xm[j];                              // (q + 0x8000) - x per half; bit 15 / 31: x <= q
+                asm("v_alignbit_b32 %0, %0, %0, 1\n\tv_bfi_b32 %0, %2, %1, %0" : "+v"(na) : "v"(d1), "s"(H));
+                const u32 e = (xh[j] ^ H) ^ q2;                         // x2 ^ q2 (xh = x2 | H)
+                mn = __builtin_elementwise_min(mn, __builtin_bit_cast(u16x2, e));
+            }
+            const u32 un = ~na | nanbits;
+            if (i < n) {
+                o.m32[((size_t)b * 2 * W32 + k) * n + i] = un;
+                if (mn.x == 0 || mn.y == 0 || nanbits) o.dflag[(size_t)b * n + i] = 1;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const u32 q2 = qv[j];
+                const u32 d1 = q2 - xm[j];                              // (q + 0x8000) - x per half; bit 15 / 31: x <= q
+                const u32 d2 = xh[j] - q2;                              // (x + 0x8000) - q per half; bit 15 / 31: x >= q
+                // rotate right by one, then take bits 15 and 31 from the difference (the compiler's own rendering of
+                // this costs a third instruction)
+                asm("v_alignbit_b32 %0, %0, %0, 1\n\tv_bfi_b32 %0, %2, %1, %0" : "+v"(na) : "v"(d1), "s"(H));
+                asm("v_alignbit_b32 %0, %0, %0, 1\n\tv_bfi_b32 %0, %2, %1, %0" : "+v"(nb_) : "v"(d2), "s"(H));
+            }
+            strict_store_masks(o, b, k, W32, n, i, (~na | nanbits) & valid, (~nb_ | nanbits) & valid, valid);
         }
-        strict_store_masks(o, b, k, W32, n, i, (~na | nanbits) & valid, (~nb_ | nanbits) & valid, valid);
         qv = qn;
         b = bn;
     }
