@@ -52,7 +52,7 @@ size_t bd_strict_workspace_bytes(i64 T, i64 n, i64 m, int J) {
            align_up((size_t)b * (strict_table_slots(n) * 16 + 16 + ((n + 63) / 64) * 8), 256) +
            align_up((size_t)((T + 31) / 32) * 4, 256) + align_up((size_t)b * ((T + 31) / 32) * 256, 256) +
            align_up((size_t)b * n * 8, 256) + align_up((size_t)b * n, 256) + align_up((size_t)(b + 1) * 4, 256) +
-           (n <= ST_RANK_MAXN ? align_up((size_t)T * n * 4, 256) + align_up((size_t)T * 4, 256) : 0) + 2560;
+           (n <= ST_RANK_MAXN ? align_up((size_t)T * n * 4, 256) + 2 * align_up((size_t)T * 4, 256) : 0) + 2560;
 }
 
 // masks[b][i][0..W) = UN, masks[b][i][W..2W) = DN
@@ -183,6 +183,7 @@ struct StrictMaskOut {
     u32 *m32;
     unsigned char *dflag;      // null: FULL
     const u32 *cmask;          // with dflag: timepoints that do not count
+    const u32 *tiemask;        // rank kernel: timepoints at which some two curves hold the same value (null: unknown)
     const u32 *dlist;          // null: every target of the batch, else the listed ones
     const u32 *dcount;
 };
@@ -258,6 +259,20 @@ __global__ __launch_bounds__(ST_THREADS) void strict_masks2_kernel(
 // 10 000 x 1 000), and makes the mask kernel's compares 32-bit (full rate; the fp64 ones run at half) on half the
 // registers.  Rt: the batch's targets gathered as in strict_gather_targets_kernel (B only, zero beyond T).
 constexpr u32 ST_RANK_NAN = 0xFFFFFFFFu;
+// Which timepoints have two curves with the same value at all?  (A + B + 1 < number of non-NaN curves for some key of
+// the row.)  Where none has, no curve can tie with any target and the mask kernel skips the tie test.  grid = T
+__global__ __launch_bounds__(ST_THREADS) void strict_row_ties_kernel(const u32 *__restrict__ R, const u32 *__restrict__ rnan,
+                                                                    i64 n, u32 *__restrict__ tiemask) {
+    const i64 t = blockIdx.x;
+    const u32 nv = (u32)n - rnan[t];
+    bool tie = false;
+    for (i64 i = threadIdx.x; i < n; i += ST_THREADS) {
+        const u32 w = R[t * n + i];
+        tie |= w != ST_RANK_NAN && (w >> 16) + (w & 0xFFFFu) + 1u != nv;
+    }
+    if (__syncthreads_or(tie) && threadIdx.x == 0) atomicOr(&tiemask[t >> 5], 1u << (t & 31));
+}
+
 __global__ __launch_bounds__(ST_THREADS) void strict_gather_rank_targets_kernel(
     const u32 *__restrict__ R, i64 T, i64 n, const i64 *__restrict__ targets, i64 q0, u32 *__restrict__ Rt,
     u32 *__restrict__ xnan) {
@@ -306,7 +321,10 @@ __global__ __launch_bounds__(ST_THREADS) void strict_masks_rank_kernel(
     // First pass of a matching batch over a full word in which every timepoint counts: only UN is stored, and of DN
     // only "is there a tie" is wanted -- a packed running minimum of x2 ^ q2 (a zero half = equal ranks = a tie)
     // instead of the second subtract / rotate / insert: 2.5 instead of 3 instructions per timepoint.
+    // ... and where no two curves of the data set share a value at any timepoint of the word (tiemask: continuous data,
+    // everywhere) not even that: 1.5 instructions per timepoint.
     const bool un_only = o.dflag != nullptr && tl == 32 && o.cmask[k] == 0;
+    const bool no_ties = un_only && o.tiemask != nullptr && o.tiemask[k] == 0;
     // Both halves at once with plain 32-bit subtractions: each half of (q2 + H) - x2 = q2 - (x2 - H) is
     // q + 0x8000 - x > 0 (no borrow between the halves) and its bit 15 says x <= q; likewise (x2 + H) - q2 for
     // x >= q.  The accumulators rotate right by one per step and take the two bits at 15 and 31 (v_bfi): after 16
@@ -322,7 +340,17 @@ __global__ __launch_bounds__(ST_THREADS) void strict_masks_rank_kernel(
         const i64 bn = z + 1 < zend ? (o.dlist ? (i64)o.dlist[z + 1] : z + 1) : b;
         const u32x16 qn = *reinterpret_cast<const u32x16 *>(Rt + (bn * W32 + k) * 16);
         u32 na = 0, nb_ = 0;
-        if (un_only) {                                                  // block-uniform
+        if (no_ties) {                                                  // block-uniform
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const u32 d1 = qv[j] - xm[j];                           // (q + 0x8000) - x per half; bit 15 / 31: x <= q
+                asm("v_alignbit_b32 %0, %0, %0, 1\n\tv_bfi_b32 %0, %2, %1, %0" : "+v"(na) : "v"(d1), "s"(H));
+            }
+            if (i < n) {
+                o.m32[((size_t)b * 2 * W32 + k) * n + i] = ~na | nanbits;
+                if (nanbits) o.dflag[(size_t)b * n + i] = 1;
+            }
+        } else if (un_only) {                                           // block-uniform
             typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
             u16x2 mn = {0xFFFF, 0xFFFF};
 #pragma unroll
@@ -1006,11 +1034,12 @@ static int launch_bd_strict_impl(const double *Y, i64 T, i64 n, const i64 *targe
     u32 *dcount = dlist + B;
     // cross-check builds, SD_STRICT_FP64_MASKS = 1: masks from the fp64 values at any n
     const bool rankmasks = !Q && n >= 2 && n <= ST_RANK_MAXN && J == 2 && xswitch("SD_STRICT_V1") != 1 && xswitch("SD_STRICT_FP64_MASKS") != 1;
-    u32 *R = nullptr, *rnan = nullptr;
+    u32 *R = nullptr, *rnan = nullptr, *tiemask = nullptr;
     if (rankmasks) {
         R = (u32 *)cv.take((size_t)T * n * 4);
         rnan = (u32 *)cv.take((size_t)T * 4);
-        if (!R || !rnan) return fail(SD_ERR_WORKSPACE, "strict-depth workspace too small");
+        tiemask = (u32 *)cv.take((size_t)((T + 31) / 32) * 4);
+        if (!R || !rnan || !tiemask) return fail(SD_ERR_WORKSPACE, "strict-depth workspace too small");
     }
     // cross-check builds, SD_STRICT_GLOBAL_TABLE = 1: the global-memory table (the route of n > 16 384) at any n
     const bool lds_match = match && n <= ST_MATCH_LDS_MAXN && xswitch("SD_STRICT_GLOBAL_TABLE") != 1;
@@ -1038,6 +1067,9 @@ static int launch_bd_strict_impl(const double *Y, i64 T, i64 n, const i64 *targe
             int rc = launch_rank_bucket_image(Y, n, r0, T - r0 < step ? T - r0 : step, R + r0 * n, rnan + r0, s);
             if (rc) return rc;
         }
+        SD_HIP(hipMemsetAsync(tiemask, 0, (size_t)((T + 31) / 32) * 4, s));
+        hipLaunchKernelGGL(strict_row_ties_kernel, dim3((unsigned)T), dim3(ST_THREADS), 0, s, (const u32 *)R, (const u32 *)rnan, n,
+                           tiemask);
     }
     for (i64 q0 = 0; q0 < m; q0 += B) {
         i64 nb = m - q0 < B ? m - q0 : B;
@@ -1052,7 +1084,7 @@ static int launch_bd_strict_impl(const double *Y, i64 T, i64 n, const i64 *targe
             // second generation: 32-bit words, word-major image (fits the same workspace: 2 W32 n u32 <= 2 W n u64)
             dim3 g1b((unsigned)((n + ST_THREADS - 1) / ST_THREADS), (unsigned)W32, (unsigned)((nb + ST_TG - 1) / ST_TG));
             // with matching, the first pass stores UN words and dirty flags only (see StrictMaskOut)
-            StrictMaskOut mo{(u32 *)masks, match ? dflag : nullptr, cmask, nullptr, nullptr};
+            StrictMaskOut mo{(u32 *)masks, match ? dflag : nullptr, cmask, tiemask, nullptr, nullptr};
             if (match) SD_HIP(hipMemsetAsync(dflag, 0, (size_t)nb * n, s));
             if (rankmasks) {
                 hipLaunchKernelGGL(strict_gather_rank_targets_kernel, dim3((unsigned)nb), dim3(ST_THREADS), 0, s, (const u32 *)R, T, n,
@@ -1087,7 +1119,7 @@ static int launch_bd_strict_impl(const double *Y, i64 T, i64 n, const i64 *targe
                 gate = dirty;
                 if (gen2) {
                     // second pass: full masks (UN and DN) for the targets on the pair kernel's work list
-                    StrictMaskOut mf{(u32 *)masks, nullptr, cmask, dlist, dcount};
+                    StrictMaskOut mf{(u32 *)masks, nullptr, cmask, tiemask, dlist, dcount};
                     if (rankmasks)
                         hipLaunchKernelGGL(strict_masks_rank_kernel, g1b, dim3(ST_THREADS), 0, s, (const u32 *)R, (const u32 *)Yt, T, n, nb,
                                            mf);
