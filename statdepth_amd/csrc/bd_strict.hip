@@ -674,6 +674,7 @@ __device__ __forceinline__ bool strict_same_canonical(const u32 *__restrict__ mb
 // count(side 0) * count(side 1).  Also writes the target's dirty bitmap and count for the pair kernel, and its total.
 constexpr i64 ST_MATCH_LDS_MAXN = 13107;                      // 16 384 slots (128 KiB) at a load of 0.8 at most
 constexpr int ST_ML_THREADS = 1024;
+constexpr int ST_ML_SEEN = 65536;                             // bits per side of the "digest seen" filter (2 x 8 KiB of LDS)
 static inline i64 strict_lds_slots(i64 n) {
     i64 s = 64;
     while (s * 4 < n * 5) s <<= 1;
@@ -698,10 +699,14 @@ __global__ __launch_bounds__(ST_ML_THREADS) void strict_match_lds_kernel(
     const u32 *mb = m32 + (size_t)b * 2 * W32 * n;
     const u64 *hb = HF + (size_t)b * n;
     u32 *cntl = tabl + slots;
-    for (int e = tid; e < 2 * slots; e += ST_ML_THREADS) tabl[e] = 0;
+    u32 *seen = cntl + slots;                                 // [2][ST_ML_SEEN / 32]: digests present on side 0 / side 1
+    for (int e = tid; e < 2 * slots + 2 * (ST_ML_SEEN / 32); e += ST_ML_THREADS) tabl[e] = 0;
     __syncthreads();
     u64 acc = 0;
     u32 z0 = 0, z1 = 0, nd = 0;
+    // Pass 1: dirty curves, the two empty-mask counts, and one bit per (side, digest): a curve can only pair with a
+    // curve whose canonical mask -- hence digest -- it shares on the OTHER side, and in continuous data hardly any
+    // digest occurs on both sides.  One LDS atomic per curve, no probing.
     for (i64 a0 = 0; a0 < n; a0 += ST_ML_THREADS) {
         const i64 a = a0 + tid;
         const bool active = a < n && a != tg;
@@ -717,7 +722,21 @@ __global__ __launch_bounds__(ST_ML_THREADS) void strict_match_lds_kernel(
                 z0 += side == 0;
                 z1 += side == 1;
             } else {
-                const u64 h = strict_spread(hf);
+                const u32 bit = (u32)(strict_spread(hf) >> 24) & (ST_ML_SEEN - 1);
+                atomicOr(&seen[side * (ST_ML_SEEN / 32) + (bit >> 5)], 1u << (bit & 31));
+            }
+        }
+    }
+    __syncthreads();
+    // Pass 2: only the curves whose digest was seen on the other side enter the table (digests again from L2).
+    for (i64 a0 = 0; a0 < n; a0 += ST_ML_THREADS) {
+        const i64 a = a0 + tid;
+        const u64 hf = a < n ? hb[a] : 0;
+        if (a < n && a != tg && (hf & 3) == 3) {
+            const u32 side = (u32)(hf >> 2) & 1u;
+            const u64 h = strict_spread(hf);
+            const u32 bit = (u32)(h >> 24) & (ST_ML_SEEN - 1);
+            if ((seen[(1u - side) * (ST_ML_SEEN / 32) + (bit >> 5)] >> (bit & 31)) & 1u) {
                 const u32 tag = ((u32)(h >> 40) & 0x3FFFu) | 0x4000u;       // 15 bits, never zero
                 const u32 mine = (tag << 17) | (side << 16) | (u32)a;
                 int slot = (int)(h & (u64)(slots - 1));
@@ -1102,7 +1121,7 @@ static int launch_bd_strict_impl(const double *Y, i64 T, i64 n, const i64 *targe
                     SD_HIP(hipMemsetAsync(dirty, 0, (size_t)B * 16, s));
                     SD_HIP(hipMemsetAsync(dcount, 0, 4, s));
                     const i64 lslots = strict_lds_slots(n);
-                    const size_t tb = (size_t)lslots * 8;
+                    const size_t tb = (size_t)lslots * 8 + 2 * (ST_ML_SEEN / 8);
                     SD_HIP(hipFuncSetAttribute((const void *)strict_match_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tb));
                     hipLaunchKernelGGL(strict_match_lds_kernel, dim3((unsigned)nb), dim3(ST_ML_THREADS), tb, s, (const u32 *)masks,
                                        (const u64 *)HF, T, n, targets, q0, xnan, (const u32 *)cmask, dirty, dbits, dlist, dcount,
