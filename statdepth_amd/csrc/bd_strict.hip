@@ -28,7 +28,7 @@ constexpr int ST_WREG = 16;          // mask words kept in registers (T <= 1024)
 static inline i64 strict_words(i64 T) { return (T + 63) / 64; }
 
 // complement matching (see strict_match_insert_kernel): open-addressing table per target, slot = 64-bit key + two counters
-constexpr i64 ST_MATCH_MAXN = 65535;                     // the key carries a 16-bit curve id
+constexpr i64 ST_MATCH_MAXN = 131071;                    // the keys carry a 17-bit curve id
 static inline i64 strict_table_slots(i64 n) {
     i64 s = 64;
     while (s < 2 * n) s <<= 1;
@@ -667,17 +667,17 @@ __device__ __forceinline__ bool strict_same_canonical(const u32 *__restrict__ mb
     return diff == 0;
 }
 
-// n <= ST_MATCH_LDS_MAXN: one block per target, the table in LDS (8 bytes per slot: key = 15 tag bits | side | 16-bit id
+// One block per target, the table in LDS (8 bytes per slot: key = 14 tag bits | side | 17-bit id
 // of the first curve with that canonical mask; counter = members after the first, side 0 in the low half, side 1 in
 // the high half).  A curve that meets its own canonical mask joins the group with one LDS atomic on the counter; the
 // value it gets back is the group before it, so `members on the other side so far` summed over the joiners is exactly
 // count(side 0) * count(side 1).  Also writes the target's dirty bitmap and count for the pair kernel, and its total.
-constexpr i64 ST_MATCH_LDS_MAXN = 13107;                      // 16 384 slots (128 KiB) at a load of 0.8 at most
+constexpr i64 ST_MATCH_LDS_CAP = 13107;                       // candidates the LDS table takes: 16 384 slots (128 KiB), load 0.8
 constexpr int ST_ML_THREADS = 1024;
 constexpr int ST_ML_SEEN = 65536;                             // bits per side of the "digest seen" filter (2 x 8 KiB of LDS)
 static inline i64 strict_lds_slots(i64 n) {
     i64 s = 64;
-    while (s * 4 < n * 5) s <<= 1;
+    while (s * 4 < n * 5 && s < 16384) s <<= 1;
     return s;
 }
 __device__ __forceinline__ u64 strict_spread(u64 hf) {        // slot and tag bits from the payload (exact ones are not hashed yet)
@@ -687,7 +687,8 @@ __device__ __forceinline__ u64 strict_spread(u64 hf) {        // slot and tag bi
 __global__ __launch_bounds__(ST_ML_THREADS) void strict_match_lds_kernel(
     const u32 *__restrict__ m32, const u64 *__restrict__ HF, i64 T, i64 n, const i64 *__restrict__ targets, i64 q0,
     const u32 *__restrict__ xnan, const u32 *__restrict__ cmask, u32 *__restrict__ meta, u64 *__restrict__ dbits,
-    u32 *__restrict__ dlist, u32 *__restrict__ dcount, int slots, int whole_targets, u64 *__restrict__ out, int jcols) {
+    u32 *__restrict__ dlist, u32 *__restrict__ dcount, int slots, int whole_targets, int force_overflow,
+    u64 *__restrict__ out, int jcols) {
     extern __shared__ u32 tabl[];                             // keys [slots] | counters [slots]
     __shared__ u64 red[ST_ML_THREADS / 64][3];
     const i64 b = blockIdx.x;
@@ -728,8 +729,23 @@ __global__ __launch_bounds__(ST_ML_THREADS) void strict_match_lds_kernel(
         }
     }
     __syncthreads();
-    // Pass 2: only the curves whose digest was seen on the other side enter the table (digests again from L2).
+    // How many candidates?  The table takes slots * 0.8 of them (n <= 13 107: always enough); a target with more -- data
+    // built of mirrored curves -- is flagged and its groups are formed in the global-memory table by the kernels below.
+    int cand = 0;
     for (i64 a0 = 0; a0 < n; a0 += ST_ML_THREADS) {
+        const i64 a = a0 + tid;
+        const u64 hf = a < n ? hb[a] : 0;
+        bool c = false;
+        if (a < n && a != tg && (hf & 3) == 3) {
+            const u32 side = (u32)(hf >> 2) & 1u;
+            const u32 bit = (u32)(strict_spread(hf) >> 24) & (ST_ML_SEEN - 1);
+            c = (seen[(1u - side) * (ST_ML_SEEN / 32) + (bit >> 5)] >> (bit & 31)) & 1u;
+        }
+        cand += __syncthreads_count(c);
+    }
+    const bool overflow = force_overflow || (i64)cand * 5 > (i64)slots * 4;     // block-uniform
+    // Pass 2: only the curves whose digest was seen on the other side enter the table (digests again from L2).
+    for (i64 a0 = 0; a0 < n && !overflow; a0 += ST_ML_THREADS) {
         const i64 a = a0 + tid;
         const u64 hf = a < n ? hb[a] : 0;
         if (a < n && a != tg && (hf & 3) == 3) {
@@ -737,8 +753,8 @@ __global__ __launch_bounds__(ST_ML_THREADS) void strict_match_lds_kernel(
             const u64 h = strict_spread(hf);
             const u32 bit = (u32)(h >> 24) & (ST_ML_SEEN - 1);
             if ((seen[(1u - side) * (ST_ML_SEEN / 32) + (bit >> 5)] >> (bit & 31)) & 1u) {
-                const u32 tag = ((u32)(h >> 40) & 0x3FFFu) | 0x4000u;       // 15 bits, never zero
-                const u32 mine = (tag << 17) | (side << 16) | (u32)a;
+                const u32 tag = ((u32)(h >> 40) & 0x1FFFu) | 0x2000u;       // 14 bits, never zero
+                const u32 mine = (tag << 18) | (side << 17) | (u32)a;       // a < 2^17
                 int slot = (int)(h & (u64)(slots - 1));
                 for (int probe = 0; probe < slots; ++probe) {                // load <= 0.8: always ends early
                     u32 cur = __hip_atomic_load(&tabl[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -746,11 +762,11 @@ __global__ __launch_bounds__(ST_ML_THREADS) void strict_match_lds_kernel(
                         cur = atomicCAS(&tabl[slot], 0u, mine);
                         if (cur == 0) break;
                     }
-                    if ((cur >> 17) == tag) {
-                        const i64 rep = (i64)(cur & 0xFFFFu);
+                    if ((cur >> 18) == tag) {
+                        const i64 rep = (i64)(cur & 0x1FFFFu);
                         const u64 hr = hb[rep];
                         if (strict_same_canonical(mb, n, W32, lastvalid, cmask, a, hf, rep, hr)) {
-                            const u32 rside = (cur >> 16) & 1u;
+                            const u32 rside = (cur >> 17) & 1u;
                             const u32 old = atomicAdd(&cntl[slot], side ? 0x10000u : 1u);
                             acc += side ? (old & 0xFFFFu) + (rside == 0) : (old >> 16) + (rside == 1);
                             break;
@@ -773,56 +789,48 @@ __global__ __launch_bounds__(ST_ML_THREADS) void strict_match_lds_kernel(
         u64 t0 = 0, t1 = 0, t2 = 0;
         for (int k = 0; k < ST_ML_THREADS / 64; ++k) { t0 += red[k][0]; t1 += red[k][1]; t2 += red[k][2]; }
         meta[b * 4] = (u32)t2;
+        meta[b * 4 + 3] = overflow ? 1u : 0u;                 // the global-table kernels add this target's groups
         if (t2) dlist[atomicAdd(dcount, 1u)] = (u32)b;        // the pair kernel's work list
         // with whole_targets the pair kernel that follows counts ALL pairs of a target that has dirty curves
         if (!(whole_targets && t2)) out[(q0 + b) * jcols] = t0 + (t1 >> 32) * (t1 & 0xFFFFFFFFull);
     }
 }
 
-// n > ST_MATCH_LDS_MAXN: the table in global memory (64-bit keys: 48 tag bits | id; two counters per slot).
+// Targets the LDS kernel flagged (meta[b][3]: more candidates than its table takes): the same grouping in a table in
+// global memory (64-bit keys: 47 tag bits | 17-bit id; two counters per slot; >= 2n slots).  The LDS kernel has done
+// the rest (dirty curves, empty masks, work list, out = z0 * z1); these kernels add the groups' products.
+// grid = (ceil(slots / 4096), nb): zero the flagged targets' tables
+__global__ __launch_bounds__(ST_THREADS) void strict_match_clear_kernel(const u32 *__restrict__ meta, unsigned long long *__restrict__ keys,
+                                                                       u32 *__restrict__ cnt, i64 slots) {
+    const i64 b = blockIdx.y;
+    if (!meta[b * 4 + 3]) return;
+    const i64 i0 = (i64)blockIdx.x * 4096;
+    for (i64 i = i0 + threadIdx.x; i < i0 + 4096 && i < slots; i += ST_THREADS) {
+        keys[(size_t)b * slots + i] = 0;
+        cnt[((size_t)b * slots + i) * 2] = 0;
+        cnt[((size_t)b * slots + i) * 2 + 1] = 0;
+    }
+}
+
 // grid = (ceil(n / 256), nb)
 __global__ __launch_bounds__(ST_THREADS) void strict_match_insert_kernel(
     const u32 *__restrict__ m32, const u64 *__restrict__ HF, i64 T, i64 n, const i64 *__restrict__ targets, i64 q0,
-    const u32 *__restrict__ xnan, const u32 *__restrict__ cmask, u32 *__restrict__ meta, u64 *__restrict__ dbits,
+    const u32 *__restrict__ xnan, const u32 *__restrict__ cmask, const u32 *__restrict__ meta,
     unsigned long long *__restrict__ keys, u32 *__restrict__ cnt, i64 slots) {
     const i64 b = blockIdx.y;
-    if (xnan[b]) return;
+    if (xnan[b] || !meta[b * 4 + 3]) return;
     const i64 tg = targets ? targets[q0 + b] : q0 + b;
     const i64 a = (i64)blockIdx.x * ST_THREADS + threadIdx.x;
-    if (a >= n) return;
+    if (a >= n || a == tg) return;
     const int W32 = (int)((T + 31) / 32);
     const u32 lastvalid = (T & 31) ? ((1u << (T & 31)) - 1u) : 0xFFFFFFFFu;
     const u32 *mb = m32 + (size_t)b * 2 * W32 * n;
     const u64 hf = HF[(size_t)b * n + a];
-    const bool clean = hf & 1;
+    if ((hf & 3) != 3) return;                                // dirty, or the empty canonical mask: counted already
     const u32 side = (u32)(hf >> 2) & 1u;
-    // dirty curves: one bit each for the pair kernel (this wave owns word a / 64 of the target's bitmap), and their
-    // number -- one atomic per wave, with ties nearly every lane is dirty
-    {
-        const bool isdirty = !clean && a != tg;
-        const u64 nd = __ballot(isdirty);
-        const int lane = threadIdx.x & 63;
-        if (lane == __ffsll((long long)__ballot(1)) - 1) {
-            dbits[(size_t)b * ((n + 63) / 64) + (a >> 6)] = nd;
-            if (nd) atomicAdd(&meta[b * 4], (u32)__popcll(nd));
-        }
-        if (!clean || a == tg) return;
-    }
-    // the empty canonical mask -- curves below the target throughout (side 0) or above it throughout (side 1) -- is the
-    // one big group of banded data: counted per wave with two ballots instead of n atomics on one table slot
-    {
-        const bool empty = !(hf & 2);
-        const u64 z0 = __ballot(empty && side == 0), z1 = __ballot(empty && side == 1);
-        if (empty) {
-            const int lane = threadIdx.x & 63;
-            if (z0 && lane == __ffsll((long long)z0) - 1) atomicAdd(&meta[b * 4 + 1], (u32)__popcll(z0));
-            if (z1 && lane == __ffsll((long long)z1) - 1) atomicAdd(&meta[b * 4 + 2], (u32)__popcll(z1));
-            return;
-        }
-    }
     const u64 h = strict_spread(hf);
-    const u64 tag = (h >> 16) | ((u64)1 << 47);               // 48 bits, never zero
-    const unsigned long long mine = (tag << 16) | (u64)a;
+    const u64 tag = (h >> 17) | ((u64)1 << 46);               // 47 bits, never zero
+    const unsigned long long mine = (tag << 17) | (u64)a;
     unsigned long long *kb = keys + (size_t)b * slots;
     u32 *cb = cnt + (size_t)b * slots * 2;
     i64 slot = (i64)(h & (u64)(slots - 1));
@@ -832,8 +840,8 @@ __global__ __launch_bounds__(ST_THREADS) void strict_match_insert_kernel(
             cur = atomicCAS(&kb[slot], 0ull, mine);
             if (cur == 0) break;
         }
-        if ((cur >> 16) == tag) {
-            const i64 rep = (i64)(cur & 0xFFFF);
+        if ((cur >> 17) == tag) {
+            const i64 rep = (i64)(cur & 0x1FFFF);
             if (strict_same_canonical(mb, n, W32, lastvalid, cmask, a, hf, rep, HF[(size_t)b * n + rep])) break;
         }
         slot = (slot + 1) & (slots - 1);
@@ -841,20 +849,19 @@ __global__ __launch_bounds__(ST_THREADS) void strict_match_insert_kernel(
     atomicAdd(&cb[slot * 2 + side], 1u);
 }
 
-// grid = (nb, ceil(slots / ST_TOTAL_CHUNK)): contained pairs of clean curves (the pair kernel adds those with a dirty member)
+// grid = (nb, ceil(slots / ST_TOTAL_CHUNK)): the flagged targets' sums of count(side 0) * count(side 1)
 constexpr int ST_TOTAL_CHUNK = 4096;
 __global__ __launch_bounds__(ST_THREADS) void strict_match_total_kernel(
     const u32 *__restrict__ cnt, i64 slots, i64 q0, const u32 *__restrict__ xnan, const u32 *__restrict__ meta,
-    u32 *__restrict__ dlist, u32 *__restrict__ dcount, int whole_targets, u64 *__restrict__ out, int jcols) {
+    int whole_targets, u64 *__restrict__ out, int jcols) {
     __shared__ u64 scratch[ST_THREADS / 64];
     const i64 b = blockIdx.x;
-    if (xnan[b]) return;
-    if (blockIdx.y == 0 && threadIdx.x == 0 && meta[b * 4] != 0) dlist[atomicAdd(dcount, 1u)] = (u32)b;   // the pair kernel's work list
+    if (xnan[b] || !meta[b * 4 + 3]) return;
     if (whole_targets && meta[b * 4] != 0) return;   // the pair kernel that follows counts ALL pairs of such a target
     const uint2 *cb = reinterpret_cast<const uint2 *>(cnt) + (size_t)b * slots;
     const i64 i0 = (i64)blockIdx.y * ST_TOTAL_CHUNK;
     const i64 i1 = i0 + ST_TOTAL_CHUNK < slots ? i0 + ST_TOTAL_CHUNK : slots;
-    u64 acc = (threadIdx.x == 0 && blockIdx.y == 0) ? (u64)meta[b * 4 + 1] * (u64)meta[b * 4 + 2] : 0;
+    u64 acc = 0;
     for (i64 i = i0 + threadIdx.x; i < i1; i += ST_THREADS) {
         const uint2 c = cb[i];
         acc += (u64)c.x * (u64)c.y;
@@ -1060,8 +1067,10 @@ static int launch_bd_strict_impl(const double *Y, i64 T, i64 n, const i64 *targe
         tiemask = (u32 *)cv.take((size_t)((T + 31) / 32) * 4);
         if (!R || !rnan || !tiemask) return fail(SD_ERR_WORKSPACE, "strict-depth workspace too small");
     }
-    // cross-check builds, SD_STRICT_GLOBAL_TABLE = 1: the global-memory table (the route of n > 16 384) at any n
-    const bool lds_match = match && n <= ST_MATCH_LDS_MAXN && xswitch("SD_STRICT_GLOBAL_TABLE") != 1;
+    // cross-check builds, SD_STRICT_GLOBAL_TABLE = 1: every target's groups through the global-memory table (the route
+    // of targets with more candidates than the LDS table takes)
+    const bool force_global = xswitch("SD_STRICT_GLOBAL_TABLE") == 1;
+    const bool global_possible = match && (force_global || n > ST_MATCH_LDS_CAP);
     u64 *dbits = (u64 *)(tab + (size_t)B * (slots * 16 + 16));
     unsigned long long *keys = (unsigned long long *)tab;
     u32 *cnt = (u32 *)(tab + (size_t)B * slots * 8);
@@ -1117,23 +1126,22 @@ static int launch_bd_strict_impl(const double *Y, i64 T, i64 n, const i64 *targe
             if (match) {
                 hipLaunchKernelGGL(strict_hash_kernel, g1, dim3(ST_THREADS), 0, s, (const u32 *)masks, T, n, xnan, (const u32 *)cmask,
                                    (const unsigned char *)dflag, HF);
-                if (lds_match) {
-                    SD_HIP(hipMemsetAsync(dirty, 0, (size_t)B * 16, s));
-                    SD_HIP(hipMemsetAsync(dcount, 0, 4, s));
-                    const i64 lslots = strict_lds_slots(n);
-                    const size_t tb = (size_t)lslots * 8 + 2 * (ST_ML_SEEN / 8);
-                    SD_HIP(hipFuncSetAttribute((const void *)strict_match_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tb));
-                    hipLaunchKernelGGL(strict_match_lds_kernel, dim3((unsigned)nb), dim3(ST_ML_THREADS), tb, s, (const u32 *)masks,
-                                       (const u64 *)HF, T, n, targets, q0, xnan, (const u32 *)cmask, dirty, dbits, dlist, dcount,
-                                       (int)lslots, gen2 ? 0 : 1, out, jcols);
-                } else {
-                    SD_HIP(hipMemsetAsync(tab, 0, (size_t)B * (slots * 16 + 16 + dwords * 8), s));
-                    SD_HIP(hipMemsetAsync(dcount, 0, 4, s));
+                SD_HIP(hipMemsetAsync(dirty, 0, (size_t)B * 16, s));
+                SD_HIP(hipMemsetAsync(dcount, 0, 4, s));
+                const i64 lslots = strict_lds_slots(n);
+                const size_t tb = (size_t)lslots * 8 + 2 * (ST_ML_SEEN / 8);
+                SD_HIP(hipFuncSetAttribute((const void *)strict_match_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tb));
+                hipLaunchKernelGGL(strict_match_lds_kernel, dim3((unsigned)nb), dim3(ST_ML_THREADS), tb, s, (const u32 *)masks,
+                                   (const u64 *)HF, T, n, targets, q0, xnan, (const u32 *)cmask, dirty, dbits, dlist, dcount,
+                                   (int)lslots, gen2 ? 0 : 1, force_global ? 1 : 0, out, jcols);
+                if (global_possible) {
+                    hipLaunchKernelGGL(strict_match_clear_kernel, dim3((unsigned)((slots + 4095) / 4096), (unsigned)nb), dim3(ST_THREADS),
+                                       0, s, (const u32 *)dirty, keys, cnt, slots);
                     hipLaunchKernelGGL(strict_match_insert_kernel, g1, dim3(ST_THREADS), 0, s, (const u32 *)masks, (const u64 *)HF, T, n,
-                                       targets, q0, xnan, (const u32 *)cmask, dirty, dbits, keys, cnt, slots);
+                                       targets, q0, xnan, (const u32 *)cmask, (const u32 *)dirty, keys, cnt, slots);
                     hipLaunchKernelGGL(strict_match_total_kernel,
                                        dim3((unsigned)nb, (unsigned)((slots + ST_TOTAL_CHUNK - 1) / ST_TOTAL_CHUNK)), dim3(ST_THREADS),
-                                       0, s, (const u32 *)cnt, slots, q0, xnan, (const u32 *)dirty, dlist, dcount, gen2 ? 0 : 1, out, jcols);
+                                       0, s, (const u32 *)cnt, slots, q0, xnan, (const u32 *)dirty, gen2 ? 0 : 1, out, jcols);
                 }
                 gate = dirty;
                 if (gen2) {
@@ -1148,8 +1156,11 @@ static int launch_bd_strict_impl(const double *Y, i64 T, i64 n, const i64 *targe
             }
             if (gen2) {
                 if (gate) {
-                    i64 layers = 4096 / ((i64)g2.x * g2.y);            // about 4 096 blocks in all, 32 layers at least
-                    if (layers < ST_PAIR_LAYERS) layers = ST_PAIR_LAYERS;
+                    // about 8 192 blocks in all (32 layers at least while a layer is small): with no dirty target every
+                    // block only reads the list's length and leaves
+                    const i64 per_layer = (i64)g2.x * g2.y;
+                    i64 layers = (8192 + per_layer - 1) / per_layer;
+                    if (layers < ST_PAIR_LAYERS && per_layer <= 256) layers = ST_PAIR_LAYERS;
                     if (layers > nb) layers = nb;
                     dim3 g2m(g2.x, g2.y, (unsigned)layers);
                     hipLaunchKernelGGL(strict_pairs2_kernel, g2m, dim3(ST_THREADS), 0, s, (const u32 *)masks, T, n, targets, q0, xnan,
