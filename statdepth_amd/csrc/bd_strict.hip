@@ -743,16 +743,29 @@ __global__ __launch_bounds__(ST_ML_THREADS) void strict_match_lds_kernel(
         }
         cand += __syncthreads_count(c);
     }
-    const bool overflow = force_overflow || (i64)cand * 5 > (i64)slots * 4;     // block-uniform
+    // More candidates than the table takes (n in the tens of thousands: the filter fills up and lets half of the crossing
+    // curves through): the digests are dealt into `rounds` classes by hash bits of their own and the table is filled
+    // class by class (a group lies in one class); more than 16 rounds, or a class that still does not fit: flagged.
+    int rounds = (int)(((i64)cand * 5 + (i64)slots * 3 - 1) / ((i64)slots * 3));       // load 0.6 per round
+    if (rounds < 1) rounds = 1;
+    bool overflow = force_overflow || rounds > 16;                               // block-uniform
     // Pass 2: only the curves whose digest was seen on the other side enter the table (digests again from L2).
-    for (i64 a0 = 0; a0 < n && !overflow; a0 += ST_ML_THREADS) {
+    for (int rd = 0; rd < rounds && !overflow; ++rd) {
+    if (rd > 0) {
+        __syncthreads();
+        for (int e = tid; e < 2 * slots; e += ST_ML_THREADS) tabl[e] = 0;
+        __syncthreads();
+    }
+    bool stuck = false;
+    for (i64 a0 = 0; a0 < n; a0 += ST_ML_THREADS) {
         const i64 a = a0 + tid;
         const u64 hf = a < n ? hb[a] : 0;
         if (a < n && a != tg && (hf & 3) == 3) {
             const u32 side = (u32)(hf >> 2) & 1u;
             const u64 h = strict_spread(hf);
             const u32 bit = (u32)(h >> 24) & (ST_ML_SEEN - 1);
-            if ((seen[(1u - side) * (ST_ML_SEEN / 32) + (bit >> 5)] >> (bit & 31)) & 1u) {
+            if ((int)((u32)(h >> 53) % (u32)rounds) == rd &&
+                ((seen[(1u - side) * (ST_ML_SEEN / 32) + (bit >> 5)] >> (bit & 31)) & 1u)) {
                 const u32 tag = ((u32)(h >> 40) & 0x1FFFu) | 0x2000u;       // 14 bits, never zero
                 const u32 mine = (tag << 18) | (side << 17) | (u32)a;       // a < 2^17
                 int slot = (int)(h & (u64)(slots - 1));
@@ -773,10 +786,14 @@ __global__ __launch_bounds__(ST_ML_THREADS) void strict_match_lds_kernel(
                         }
                     }
                     slot = (slot + 1) & (slots - 1);
+                    stuck |= probe == slots - 1;                             // table full: never with load 0.6, but exact
                 }
             }
         }
     }
+    if (__syncthreads_or(stuck)) overflow = true;
+    }                                                                         // rounds
+    if (overflow) acc = 0;                                                    // the global-memory table counts ALL groups
     u64 r0 = acc, r1 = ((u64)z0 << 32) | z1, r2 = nd;
     for (int o = 32; o > 0; o >>= 1) {
         r0 += __shfl_down(r0, o);
