@@ -38,7 +38,11 @@ static inline bool strict_match_applies(i64 T, i64 n, int J) { return J == 2 && 
 
 static i64 strict_batch(i64 T, i64 n, i64 m) {
     size_t per = (size_t)n * 2 * strict_words(T) * 8 + (size_t)strict_table_slots(n) * 16 + 20 + (size_t)((n + 63) / 64) * 8 + (size_t)((T + 31) / 32) * 256 + (size_t)n * 9;
-    i64 b = (i64)(((size_t)2048 << 20) / (per ? per : 1));   // up to 2 GiB of masks and tables per batch
+    i64 b = (i64)(((size_t)2048 << 20) / (per ? per : 1));   // up to 2 GiB of masks and tables per batch ...
+    if (b < 1024) {                                           // ... or 16 GiB when that is what 1024 targets take: the matching
+        const i64 b16 = (i64)(((size_t)16384 << 20) / (per ? per : 1));   // kernel runs one workgroup per target
+        b = b16 < 1024 ? b16 : 1024;
+    }
     if (b < 1) b = 1;
     if (b > m) b = m;
     if (b > 65535) b = 65535;
