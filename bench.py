@@ -233,6 +233,12 @@ def extras_multi_gpu(torch, dist, dev, rank, N, reps=5):
         dt = tmax(dt)
         out[f"config3_{mode}"] = {"workload": f"MBD J=2, {n} curves x {T} timepoints over {N} GPUs ({mode}-sharded)",
                                   "scaling": "strong", "ms": dt / reps * 1e3, "curve_pairs_per_s": float(n) * (n - 1) / (dt / reps)}
+    # strict band depth (the reference's default relax=False) of the same curves: targets sharded, one all-gather
+    from statdepth_amd.distributed import sharded_bd_strict_counts
+    dt, _ = timed(lambda _: sharded_bd_strict_counts(X_loc, J=2, sizes=sizes), 1, 1, stream, torch, barrier)
+    dt = tmax(dt)
+    out["config3_strict_targets"] = {"workload": f"strict band depth J=2, {n} curves x {T} timepoints over {N} GPUs (target-sharded)",
+                                     "scaling": "strong", "ms": dt * 1e3, "targets_per_s": n / dt}
     npts = 1000000
     P_loc = torch.from_numpy(np.random.default_rng(1237 + rank).normal(size=(npts // N, 3))).to(dev)
     for cont, kw, units in (("simplex", {"samples": 4096, "seed": 1237}, npts * 4096.0), ("l1", {}, float(npts) * npts)):
