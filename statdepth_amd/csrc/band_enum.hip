@@ -50,7 +50,7 @@ __global__ __launch_bounds__(1024) void band_class_kernel(const u32 *__restrict_
     unsigned short *R = reinterpret_cast<unsigned short *>(smem);                  // [n][D] ranks at this timepoint
     u32 *h0 = reinterpret_cast<u32 *>(smem + (((size_t)n * D * 2 + 15) / 16) * 16);  // [NC] curves per state vector
     u32 *z = h0 + NC;                                                             // [NC] transformed counters
-    __shared__ u64 red[NT / 64];
+    __shared__ u64 red[NT / 64][2];
     const int t = threadIdx.x;
     const i64 tp = blockIdx.x;
     const i64 RR = T * D;
@@ -66,52 +66,90 @@ __global__ __launch_bounds__(1024) void band_class_kernel(const u32 *__restrict_
         }
     }
     __syncthreads();
-    for (i64 qi = blockIdx.y; qi < m; qi += gridDim.y) {
-        const int tg = (int)(targets ? targets[qi] : qi);
-        u32 rq[D];
+    // Two targets per sweep: their counters share the 32-bit words (low / high half: counts and transformed counts are
+    // <= n < 2^16, and every step of the transform is an addition), so zeroing, the transform and its barriers are paid
+    // once for both; the transform takes two features per pass (nine-point groups, M applied along either).
+    for (i64 q0 = 2 * (i64)blockIdx.y; q0 < m; q0 += 2 * (i64)gridDim.y) {
+        const bool two = q0 + 1 < m;
+        const int tgA = (int)(targets ? targets[q0] : q0);
+        const int tgB = two ? (int)(targets ? targets[q0 + 1] : q0 + 1) : tgA;
+        u32 rqA[D], rqB[D];
 #pragma unroll
-        for (int f = 0; f < D; ++f) rq[f] = R[(size_t)tg * D + f];
+        for (int f = 0; f < D; ++f) {
+            rqA[f] = R[(size_t)tgA * D + f];
+            rqB[f] = R[(size_t)tgB * D + f];
+        }
         for (int c = t; c < NC; c += NT) h0[c] = 0;
         __syncthreads();
         for (int a = t; a < n; a += NT) {
-            if (a == tg) continue;
-            u32 code = 0, w = 1;
+            u32 codeA = 0, codeB = 0, w = 1;
 #pragma unroll
             for (int f = 0; f < D; ++f) {
                 const u32 ra = R[(size_t)a * D + f];
-                code += w * (ra > rq[f] ? 1u : (ra < rq[f] ? 2u : 0u));
+                codeA += w * (ra > rqA[f] ? 1u : (ra < rqA[f] ? 2u : 0u));
+                codeB += w * (ra > rqB[f] ? 1u : (ra < rqB[f] ? 2u : 0u));
                 w *= 3u;
             }
-            atomicAdd(&h0[code], 1u);
+            if (a != tgA) atomicAdd(&h0[codeA], 1u);
+            if (a != tgB) atomicAdd(&h0[codeB], 0x10000u);
         }
         __syncthreads();
         for (int c = t; c < NC; c += NT) z[c] = h0[c];
         __syncthreads();
-        // z <- (M x ... x M) h: one 3-point pass per feature (the triples of a pass are disjoint: in place)
+        // z <- (M x ... x M) h, M = tie: compatible with every state; above: with tie and below; below: with tie and above
         int stride = 1;
 #pragma unroll
-        for (int f = 0; f < D; ++f) {
-            for (int i = t; i < NC / 3; i += NT) {
-                const int base = (i / stride) * stride * 3 + (i % stride);
-                const u32 s0 = z[base], s1 = z[base + stride], s2 = z[base + 2 * stride];
-                z[base] = s0 + s1 + s2;                      // tie: compatible with every state
-                z[base + stride] = s0 + s2;                  // above: with tie and below
-                z[base + 2 * stride] = s0 + s1;              // below: with tie and above
+        for (int f = 0; f < D; f += 2) {
+            if (f + 1 < D) {
+                for (int g = t; g < NC / 9; g += NT) {
+                    const int base = (g / stride) * stride * 9 + (g % stride);
+                    u32 v[3][3];
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) {
+                        const u32 s0 = z[base + (3 * j) * stride], s1 = z[base + (3 * j + 1) * stride], s2 = z[base + (3 * j + 2) * stride];
+                        v[j][0] = s0 + s1 + s2;
+                        v[j][1] = s0 + s2;
+                        v[j][2] = s0 + s1;
+                    }
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) {
+                        z[base + i * stride] = v[0][i] + v[1][i] + v[2][i];
+                        z[base + (3 + i) * stride] = v[0][i] + v[2][i];
+                        z[base + (6 + i) * stride] = v[0][i] + v[1][i];
+                    }
+                }
+                stride *= 9;
+            } else {
+                for (int i = t; i < NC / 3; i += NT) {
+                    const int base = (i / stride) * stride * 3 + (i % stride);
+                    const u32 s0 = z[base], s1 = z[base + stride], s2 = z[base + 2 * stride];
+                    z[base] = s0 + s1 + s2;
+                    z[base + stride] = s0 + s2;
+                    z[base + 2 * stride] = s0 + s1;
+                }
+                stride *= 3;
             }
-            stride *= 3;
             __syncthreads();
         }
-        u64 acc = 0;
-        for (int c = t; c < NC; c += NT) acc += (u64)h0[c] * (u64)z[c];
-        for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o);
-        if ((t & 63) == 0) red[t >> 6] = acc;
+        u64 accA = 0, accB = 0;
+        for (int c = t; c < NC; c += NT) {
+            const u32 h = h0[c], zz = z[c];
+            accA += (u64)(h & 0xFFFFu) * (u64)(zz & 0xFFFFu);
+            accB += (u64)(h >> 16) * (u64)(zz >> 16);
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            accA += __shfl_down(accA, o);
+            accB += __shfl_down(accB, o);
+        }
+        if ((t & 63) == 0) { red[t >> 6][0] = accA; red[t >> 6][1] = accB; }
         __syncthreads();
         if (t == 0) {
-            u64 ordered = 0;
-            for (int k = 0; k < NT / 64; ++k) ordered += red[k];
+            u64 oA = 0, oB = 0;
+            for (int k = 0; k < NT / 64; ++k) { oA += red[k][0]; oB += red[k][1]; }
             // a curve is compatible with itself iff it ties with the target in every feature (state vector 0)
-            const u64 pairs = (ordered - (u64)h0[0]) / 2;
-            if (pairs) atomicAdd(&out[qi], pairs);
+            const u64 pA = (oA - (u64)(h0[0] & 0xFFFFu)) / 2, pB = (oB - (u64)(h0[0] >> 16)) / 2;
+            if (pA) atomicAdd(&out[q0], pA);
+            if (two && pB) atomicAdd(&out[q0 + 1], pB);
         }
         __syncthreads();
     }
