@@ -1035,6 +1035,100 @@ int launch_bd_strict_subsets(const double *Y, i64 T, i64 n, const int *members, 
     return SD_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// J = 2 over at most three timepoints, any n: the L-infinity / box containment of point clouds (SURVEY 8 P4:
+// FunctionalDepth([points.T]) -- "curves" = points, "timepoints" = coordinates; config 5 is 10^6 points in R^3, where
+// the reference's default relax=False asks for the pairs of points whose bounding box contains the target).
+// Per (target, other point) a STATE per coordinate in two bits -- above, below, neither (tie), both (NaN) -- i.e. a
+// class c < 4^T; a pair is contained at every coordinate iff c_a & c_b == 0.  With h[c] = points per class,
+//     ordered contained pairs = sum over c, c' with c & c' == 0 of h[c] h[c'] = sum over masks (-1)^popc(mask) U[mask]^2,
+// U = superset sums of h (inclusion-exclusion over the 2T bits), so a target costs one pass over the points and a
+// 64-entry transform -- O(n) per target instead of O(n^2), exact, no limit on n.
+// Lanes = targets (coordinates in VGPRs, a private 4^T-counter histogram per lane in LDS: [class][lane], no atomics
+// between lanes); the points stream through the scalar cache, eight per load, the same for every lane of the block.
+// ---------------------------------------------------------------------------------------------------
+constexpr int ST_CL_THREADS = 128;
+template <int TT>
+__global__ __launch_bounds__(ST_CL_THREADS) void strict_class_kernel(const double *__restrict__ Y, i64 n, const i64 *__restrict__ targets,
+                                                                    const double *__restrict__ Q, i64 m, u64 *__restrict__ out,
+                                                                    int jcols) {
+    constexpr int NC = 1 << (2 * TT);
+    __shared__ u32 hist[NC][ST_CL_THREADS];
+    const int tid = threadIdx.x;
+    const i64 q = (i64)blockIdx.x * ST_CL_THREADS + tid;
+    const bool active = q < m;
+    const i64 tg = (active && !Q) ? (targets ? targets[q] : q) : -1;        // its own column is not one of the others
+    double x[TT];
+    bool tnan = false;
+#pragma unroll
+    for (int t = 0; t < TT; ++t) {
+        x[t] = !active ? 0.0 : (Q ? Q[t * m + q] : Y[t * n + tg]);
+        tnan |= x[t] != x[t];
+    }
+#pragma unroll
+    for (int c = 0; c < NC; ++c) hist[c][tid] = 0;
+    auto visit = [&](i64 i, const double (&p)[TT]) {
+        u32 code = 0;
+#pragma unroll
+        for (int t = 0; t < TT; ++t) {
+            const bool isn = p[t] != p[t];                                   // wave-uniform
+            code |= ((p[t] > x[t] || isn) ? 1u : 0u) << (2 * t);
+            code |= ((p[t] < x[t] || isn) ? 2u : 0u) << (2 * t);
+        }
+        if (i != tg) hist[code][tid] += 1u;                                  // own counter: no atomic needed
+    };
+    i64 i = 0;
+    for (; i + 8 <= n; i += 8) {
+        double blkp[TT][8];
+#pragma unroll
+        for (int t = 0; t < TT; ++t)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) blkp[t][k] = Y[t * n + i + k];      // wave-uniform addresses: scalar loads
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            double p[TT];
+#pragma unroll
+            for (int t = 0; t < TT; ++t) p[t] = blkp[t][k];
+            visit(i + k, p);
+        }
+    }
+    for (; i < n; ++i) {
+        double p[TT];
+#pragma unroll
+        for (int t = 0; t < TT; ++t) p[t] = Y[t * n + i];
+        visit(i, p);
+    }
+    if (!active) return;
+    // superset sums over the 2T bits, in place; class 0 = the points that tie with the target in every coordinate: the
+    // only ones that are compatible with themselves
+    const u64 ties = hist[0][tid];
+#pragma unroll
+    for (int bit = 1; bit < NC; bit <<= 1)
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+            if (!(c & bit)) hist[c][tid] += hist[c | bit][tid];
+    long long total = 0;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const long long u = (long long)hist[c][tid];
+        total += (__builtin_popcount((unsigned)c) & 1) ? -u * u : u * u;
+    }
+    out[q * jcols] = tnan ? 0ull : ((u64)total - ties) / 2;                  // NaN in the target: nothing is contained
+}
+
+int launch_bd_strict_classes(const double *Y, i64 T, i64 n, const i64 *targets, const double *Q, i64 m, u64 *out, int jcols,
+                             hipStream_t s) {
+    const unsigned grid = (unsigned)((m + ST_CL_THREADS - 1) / ST_CL_THREADS);
+    switch ((int)T) {
+        case 1: hipLaunchKernelGGL(strict_class_kernel<1>, dim3(grid), dim3(ST_CL_THREADS), 0, s, Y, n, targets, Q, m, out, jcols); break;
+        case 2: hipLaunchKernelGGL(strict_class_kernel<2>, dim3(grid), dim3(ST_CL_THREADS), 0, s, Y, n, targets, Q, m, out, jcols); break;
+        case 3: hipLaunchKernelGGL(strict_class_kernel<3>, dim3(grid), dim3(ST_CL_THREADS), 0, s, Y, n, targets, Q, m, out, jcols); break;
+        default: return fail(SD_ERR_UNSUPPORTED, "the class kernel covers up to three timepoints");
+    }
+    SD_HIP(hipGetLastError());
+    return SD_OK;
+}
+
 // Q != nullptr: the m targets are EXTERNAL curves (T x m, time-major), every curve of Y is an "other" (J = 2 only).
 static int launch_bd_strict_impl(const double *Y, i64 T, i64 n, const i64 *targets, const double *Q, i64 m, int J,
                                  u64 *out, void *ws, size_t ws_bytes, hipStream_t s);
@@ -1060,6 +1154,9 @@ int launch_bd_strict_external(const double *Y, i64 T, i64 n, const double *Q, i6
 
 static int launch_bd_strict_impl(const double *Y, i64 T, i64 n, const i64 *targets, const double *Q, i64 m, int J,
                                  u64 *out, void *ws, size_t ws_bytes, hipStream_t s) {
+    // cross-check builds, SD_STRICT_NOCLASS = 1: short series through the mask kernels like any other
+    if (J == 2 && T <= 3 && xswitch("SD_STRICT_V1") != 1 && xswitch("SD_STRICT_NOCLASS") != 1)
+        return launch_bd_strict_classes(Y, T, n, Q ? nullptr : targets, Q, m, out, 1, s);
     i64 W = strict_words(T);
     i64 B = strict_batch(T, n, m);
     Carver cv(ws, ws_bytes);
