@@ -163,6 +163,21 @@ def extras_single_gpu(torch, dev, stream, lib, check, ALGOS, oracle, reps=10):
     out["strict_10000x1000"] = {"workload": "strict band depth J=2, 10000 random walks x 1000 timepoints, every target", "ms": ms,
                                 "pair_tests_per_s": n * (n - 1) * (n - 2) / 2 / (ms * 1e-3), "checked_targets": len(tg)}
     del Xd, res, ws
+    # config 5 (i), the reference's default relax=False: L-infinity (box) depth of 10^6 points in R^3, every point a target
+    P6 = np.random.default_rng(1237).normal(size=(1000000, 3))
+    X6 = np.ascontiguousarray(P6.T)
+    Xd = torch.from_numpy(X6).to(dev)
+    T, n = X6.shape
+    res = torch.empty((n, 1), dtype=torch.int64, device=dev)
+    wsb = lib.sd_bd_strict_workspace_bytes(T, n, n, 1, n)
+    ws = torch.empty(int(wsb), dtype=torch.uint8, device=dev)
+    _, ms = timed(lambda _: check(lib.sd_bd_strict_counts(Xd.data_ptr(), T, n, n, 1, 0, n, res.data_ptr(), ws.data_ptr(), wsb,
+                                                         stream.cuda_stream)), 1, 1, stream, torch)
+    tg = np.array([0, 123456, 999999])
+    assert (res.cpu().numpy()[tg, 0] == oracle.bd_strict_counts_by_states(X6, tg)).all(), "strict linf 1e6"
+    out["config5_linf_strict_1e6x3"] = {"workload": "L-infinity (box) depth, relax=False, 10^6 points in R^3, every point", "ms": ms,
+                                        "point_pairs_per_s": float(n) * (n - 1) / (ms * 1e-3), "checked_targets": len(tg)}
+    del Xd, res, ws
     # L1 depth and sampled simplicial depth
     P = np.random.default_rng(1237).normal(size=(100000, 3))
     Pd = torch.from_numpy(P).to(dev)
@@ -241,6 +256,13 @@ def extras_multi_gpu(torch, dist, dev, rank, N, reps=5):
                                      "scaling": "strong", "ms": dt * 1e3, "targets_per_s": n / dt}
     npts = 1000000
     P_loc = torch.from_numpy(np.random.default_rng(1237 + rank).normal(size=(npts // N, 3))).to(dev)
+    # config 5 (i): L-infinity (box) depth, the reference's default relax=False, targets sharded
+    Xp = P_loc.t().contiguous()
+    psz = [npts // N] * N
+    dt, _ = timed(lambda _: sharded_bd_strict_counts(Xp, J=2, sizes=psz), 1, 1, stream, torch, barrier)
+    dt = tmax(dt)
+    out["config5_linf_strict"] = {"workload": f"L-infinity depth (relax=False), 10^6 points in R^3 over {N} GPUs (target-sharded)",
+                                  "scaling": "strong", "ms": dt * 1e3, "units_per_s": float(npts) * npts / dt}
     for cont, kw, units in (("simplex", {"samples": 4096, "seed": 1237}, npts * 4096.0), ("l1", {}, float(npts) * npts)):
         dt, _ = timed(lambda _: sharded_pointcloud(P_loc, cont, **kw), 2, 1, stream, torch, barrier)
         dt = tmax(dt)

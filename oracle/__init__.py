@@ -171,6 +171,39 @@ def bd_strict_counts(X, targets=None):
     return out
 
 
+def bd_strict_counts_by_states(X, targets):
+    """The same integers for SHORT series (T <= 8) at any n, in O(n * 2^(2T)) per target instead of O(n^2 T): numpy.
+
+    Per (target, other curve) the state per timepoint in two bits -- above (or NaN), below (or NaN) -- is a class c; a
+    pair {a, b} fails at t iff both are above or both are below there (`min <= x <= max`, _containment.py:76, with pandas'
+    skipna: a NaN member of the band joins both), so it is contained at every t iff c_a & c_b == 0.  With h[c] curves
+    per class the ordered contained pairs are sum over c & c' == 0 of h[c] h[c'].  Pinned against `bd_strict_counts`
+    (the restatement of _functional.py:246-251 with `c // T`) in tests/test_oracle_golden.py; used where that one's
+    O(n^2) per target is out of reach (10^6 points in R^3)."""
+    X = np.asarray(X, dtype=np.float64)
+    T, n = X.shape
+    assert T <= 8
+    tg = _targets(targets, n)
+    out = np.zeros(len(tg), dtype=np.int64)
+    NC = 1 << (2 * T)
+    cls = np.arange(NC)
+    compat = (cls[:, None] & cls[None, :]) == 0
+    for k, q in enumerate(tg):
+        x = X[:, q]
+        if np.isnan(x).any():
+            continue
+        code = np.zeros(n, dtype=np.int64)
+        for t in range(T):
+            isn = np.isnan(X[t])
+            code |= ((X[t] > x[t]) | isn).astype(np.int64) << (2 * t)
+            code |= ((X[t] < x[t]) | isn).astype(np.int64) << (2 * t + 1)
+        code = np.delete(code, q)
+        h = np.bincount(code, minlength=NC).astype(object)          # Python integers: no overflow at n = 10^6
+        ordered = sum(int(h[c]) * int(h[compat[c]].sum()) for c in range(NC) if h[c])
+        out[k] = (ordered - int(h[0])) // 2                         # class 0 (ties everywhere) is compatible with itself
+    return out
+
+
 def point_in_hull(P, x, tol=DEFAULT_TOL):
     P = np.ascontiguousarray(P, dtype=np.float64)
     x = np.ascontiguousarray(x, dtype=np.float64)

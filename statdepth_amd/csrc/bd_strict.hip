@@ -50,7 +50,8 @@ static i64 strict_batch(i64 T, i64 n, i64 m) {
 }
 
 size_t bd_strict_workspace_bytes(i64 T, i64 n, i64 m, int J) {
-    (void)J;
+    // short series go through the class kernel (launch_bd_strict_classes): a flag, no images
+    if (J == 2 && T <= 3 && xswitch("SD_STRICT_V1") != 1 && xswitch("SD_STRICT_NOCLASS") != 1) return 4096;
     i64 b = strict_batch(T, n, m);
     return align_up((size_t)b * n * 2 * strict_words(T) * 8, 256) + align_up((size_t)b * 4, 256) +
            align_up((size_t)b * (strict_table_slots(n) * 16 + 16 + ((n + 63) / 64) * 8), 256) +

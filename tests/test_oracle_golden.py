@@ -191,3 +191,19 @@ def test_oracle_is_sanitizer_clean():
     r = subprocess.run(["make", "-s", "-C", os.path.join(root, "oracle"), "sanitize"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "selftest ok" in r.stdout and "ERROR" not in r.stderr
+
+
+def test_strict_counts_by_states_equal_the_enumeration():
+    """oracle.bd_strict_counts_by_states (short series, any n) against oracle.bd_strict_counts (pair enumeration)."""
+    import oracle
+    rng = np.random.default_rng(3)
+    for T, n in [(1, 7), (2, 40), (3, 150), (4, 60)]:
+        for variant in range(3):
+            X = rng.normal(size=(T, n))
+            if variant == 1:
+                X = np.round(X * 2)
+            if variant == 2:
+                X[rng.integers(0, T), 3] = np.nan
+                X[:, 5] = X[:, 6]
+            tg = np.arange(n)
+            assert (oracle.bd_strict_counts_by_states(X, tg) == oracle.bd_strict_counts(X, tg)).all(), (T, n, variant)
