@@ -39,7 +39,7 @@ for c in range(cases):
         if cnt[i] != oracle.pointcloud_simplex_counts(F[b], [len(b) - 1])[0]:
             bad += 1; print(f"SUBSET MISMATCH case {c}: n={n} d={d} block {i}", flush=True)
     # ---- strict band depth: complement matching with every kind of curve mixed in ----
-    T = int(rng.choice([3, 17, 32, 33, 64, 95, 130, 257, 1025, 1100])); n = int(rng.integers(4, 260))
+    T = int(rng.choice([1, 2, 3, 4, 17, 32, 33, 64, 95, 130, 257, 1025, 1100])); n = int(rng.integers(4, 260))
     if rng.random() < 0.5:
         X = np.sort(rng.normal(size=n))[None, :] * rng.choice([0.5, 3.0]) + rng.normal(size=(T, n)) * rng.choice([0.05, 0.5])
     else:
