@@ -1226,6 +1226,12 @@ static int launch_bd_strict_impl(const double *Y, i64 T, i64 n, const i64 *targe
     const i64 slots = strict_table_slots(n);
     // cross-check builds, SD_STRICT_NOMATCH = 1: every target through the pair kernel
     const bool match = strict_match_applies(T, n, J) && xswitch("SD_STRICT_V1") != 1 && xswitch("SD_STRICT_NOMATCH") != 1;
+    // Without matching every pair of curves is tested for every target: refuse what would keep the GPU for hours
+    // (m n^2 / 2 pair tests at ~2e11 per second) instead of starting it
+    if (!match && J == 2 && (double)m * (double)n * (double)n * 0.5 > 2.0e14)
+        return fail(SD_ERR_UNSUPPORTED, "strict band depth of %lld curves over %lld timepoints: pairs are counted by matching for up to "
+                    "%lld curves (any number for T <= 3); beyond that every pair is tested, %.1e tests here", (long long)n,
+                    (long long)T, (long long)ST_MATCH_MAXN, (double)m * (double)n * (double)n * 0.5);
     const i64 dwords = (n + 63) / 64;
     // keys | counters | per target {dirty, below, above, -} | dirty bitmaps
     unsigned char *tab = (unsigned char *)cv.take((size_t)B * (slots * 16 + 16 + dwords * 8));
