@@ -1,4 +1,4 @@
-// bd_strict.hip -- K3: strict band depth (relax=False).
+// bd_strict.hip -- K3: strict band depth (relax=False, the reference's default).
 //
 // Replaces the subset loop of _univariate_band_depth (_functional.py:246-251) with
 // `containment // len(curve)` (_containment.py:80): a j-subset of the other curves
@@ -10,9 +10,20 @@
 // its members are in UN or all are in DN, so it is contained at every t iff
 //   AND_members(UN) == 0 and AND_members(DN) == 0      (as T-bit masks).
 // A NaN in the target fails everything (count 0).
-// Phase 1 builds the masks (coalesced row reads, target value wave-uniform);
-// phase 2 counts subsets: lanes = curve a (masks in VGPRs), partner b wave-uniform
-// through the scalar cache.  Integer work, VALU-bound (64-bit AND/OR), no MFMA.
+//
+// What runs, by case (launch_bd_strict_impl):
+//   J = 2, T <= 3, any n      strict_class_kernel: the masks ARE classes (4^T or 3^T of them); per target one pass over
+//                             the curves and a class transform.  The L-infinity depth of point clouds.
+//   J = 2, n <= 131 071       per batch of targets: masks (strict_masks_rank_kernel from the bucket kernel's rank image
+//                             for n <= 16 384, else strict_masks2_kernel from the values) -> digests of the canonical
+//                             masks (strict_hash_kernel) -> pairs of CLEAN curves counted by grouping complementary
+//                             masks (strict_match_lds_kernel; global-memory table behind it) -> pairs with a DIRTY
+//                             curve (tie / NaN) tested by strict_pairs2_kernel, for the targets that have any.
+//                             T > 1024: those targets through the first generation instead.
+//   J = 2, n > 131 071        pair kernel for every pair (refused when that would take hours).
+//   J = 3, 4                  first-generation masks + prefix enumeration (small n, like the reference).
+//   external targets, explicit blocks: launch_bd_strict_external, launch_bd_strict_subsets.
+// Integer / compare work throughout: VALU-issue and LDS bound, no MFMA.
 #include <stdlib.h>
 
 #include "sd_common.h"
@@ -27,7 +38,7 @@ constexpr int ST_WREG = 16;          // mask words kept in registers (T <= 1024)
 
 static inline i64 strict_words(i64 T) { return (T + 63) / 64; }
 
-// complement matching (see strict_match_insert_kernel): open-addressing table per target, slot = 64-bit key + two counters
+// complement matching: the global-memory table behind the LDS one (strict_match_insert_kernel): slot = 64-bit key + two counters
 constexpr i64 ST_MATCH_MAXN = 131071;                    // the keys carry a 17-bit curve id
 static inline i64 strict_table_slots(i64 n) {
     i64 s = 64;
