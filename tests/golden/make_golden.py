@@ -219,6 +219,26 @@ def build_cases():
         add(lambda name, relax=relax: univariate_case(name, g10(), "_functional.py:198-255", J=2, relax=relax),
             f"g10_walk_37x23_{'relax' if relax else 'strict'}")
 
+    # G12: what the strict path's complement matching treats specially -- curves sharing their first value (a constant
+    # timepoint), mirrored curves (complementary masks on purpose), a curve that touches another once (sparse tie), and
+    # more than 32 timepoints (two mask words) -- from the reference itself
+    def g12(kind):
+        rng = np.random.default_rng(212)
+        T, n = 40, 16
+        X = np.sort(rng.normal(size=n))[None, :] * 1.5 + rng.normal(size=(T, n)).cumsum(axis=0) * 0.15
+        if kind == "common_start":
+            X = X - X[0:1, :]
+        elif kind == "mirrored":
+            X[:, n // 2:] = -X[:, : n // 2]
+            X[:, 0] = 0.0
+        elif kind == "touch":
+            X[17, 3] = X[17, 9]
+            X[29, 5] = X[29, 6]
+        return pd.DataFrame(X, columns=[f"c{i}" for i in range(n)])
+    for kind in ("common_start", "mirrored", "touch"):
+        add(lambda name, kind=kind: univariate_case(name, g12(kind), "_functional.py:198-255", J=2, relax=False),
+            f"g12_{kind}_strict")
+
     # G9 K-sampled ----------------------------------------------------------
     def g9(name):
         R = _ref()
