@@ -389,6 +389,27 @@ def build_cases():
     for m in ("p1", "p2", "p3"):
         add(lambda name, m=m: homog_case(name, m), f"h_{m}")
 
+    # the same with the reference's default relax=False (the strict depth of every g inside F u {g}); banded samples so
+    # that strict depths are not all zero
+    def homog_strict_case(name, method):
+        if REF not in sys.path:
+            sys.path.insert(0, REF)
+        from statdepth.homogeneity import FunctionalHomogeneity
+        rng = np.random.default_rng(53)
+        F = pd.DataFrame(np.sort(rng.normal(size=11))[None, :] * 2.0 + rng.normal(size=(12, 11)) * 0.2,
+                         columns=[f"F{i}" for i in range(11)])
+        G = pd.DataFrame(np.sort(rng.normal(size=8))[None, :] * 1.5 + rng.normal(size=(12, 8)) * 0.2 + 0.1,
+                         columns=[f"G{i}" for i in range(8)])
+        t0 = time.time()
+        val = FunctionalHomogeneity([F.copy()], [G.copy()], method=method, relax=False, quiet=True).homogeneity()
+        val = np.asarray(val, dtype=float).ravel()
+        return {"name": name, "kind": "homogeneity", "ref": "homogeneity.py:65-153",
+                "call": {"method": method, "relax": False, "J": 2},
+                "input": {"F": _frame_json(F), "G": _frame_json(G)},
+                "value": [_enc(v) for v in val], "elapsed_s": time.time() - t0}
+    for m in ("p1", "p3"):
+        add(lambda name, m=m: homog_strict_case(name, m), f"h_{m}_strict")
+
     # the function forms P1_homogeneity / P2_homogeneity (homogeneity.py:214-306).  NB the reference's P1 leaves its
     # 'G_deepest' column in the caller's F, and P2 then takes F's deepest depth WITH that column present.
     def homog_fn_case(name, which, relax):
