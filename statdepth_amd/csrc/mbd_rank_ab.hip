@@ -528,4 +528,46 @@ int launch_mbd_rank(const double *Y, i64 T, i64 n, const i64 *targets, i64 tbegi
     return SD_OK;
 }
 
+// 16 384 < n <= 24 576: pair image by rank_medium_image_kernel (two column blocks per workgroup, mbd_rank_bucket.hip),
+// folded by the same accumulate kernels as the bucket kernel's image mode.
+bool rank_medium_supported(i64 n);
+int launch_rank_medium_image(const double *Y, i64 n, i64 row0, i64 rows, u32 *AB, u32 *nnan, hipStream_t s);
+
+bool mbd_rank_medium_supported(i64 T, i64 n, int J) {
+    (void)T;
+    return rank_medium_supported(n) && J >= 2 && J <= JMAX && xswitch("SD_BIG_NOMEDIUM") != 1;
+}
+
+size_t mbd_rank_medium_workspace_bytes(i64 T, i64 n, int J) {
+    if (!mbd_rank_medium_supported(T, n, J)) return 0;
+    const i64 rpb = ab_rows_per_batch(T, n);
+    return align_up((size_t)rpb * n * 4, 256) + align_up((size_t)rpb * 4, 256) + 512;
+}
+
+int launch_mbd_rank_medium(const double *Y, i64 T, i64 n, const i64 *targets, i64 tbegin, i64 m, int J, u64 *out, void *ws,
+                           size_t ws_bytes, hipStream_t s) {
+    if (!mbd_rank_medium_supported(T, n, J)) return fail(SD_ERR_UNSUPPORTED, "medium rank route covers 16384 < n <= 24576");
+    const i64 rpb = ab_rows_per_batch(T, n);
+    Carver cv(ws, ws_bytes);
+    u32 *AB = (u32 *)cv.take((size_t)rpb * n * 4);
+    u32 *nnan = (u32 *)cv.take((size_t)rpb * 4);
+    if (!AB || !nnan) return fail(SD_ERR_WORKSPACE, "rank workspace too small (medium route)");
+    for (i64 row0 = 0; row0 < T; row0 += rpb) {
+        const i64 rows = T - row0 < rpb ? T - row0 : rpb;
+        int rc = launch_rank_medium_image(Y, n, row0, rows, AB, nnan, s);
+        if (rc) return rc;
+        dim3 grid((unsigned)((m + 63) / 64));
+        const int first = row0 == 0;
+        if (!targets && (n % 4) == 0 && (tbegin % 4) == 0 && (m % 4) == 0 && J <= 3) {
+            SD_DISPATCH_J(J, hipLaunchKernelGGL((rank_accumulate4_kernel<J_>), grid, dim3(1024), 0, s, (const u32 *)AB,
+                                                (const u32 *)nnan, rows, n, tbegin, m, out, first));
+        } else {
+            SD_DISPATCH_J(J, hipLaunchKernelGGL((rank_accumulate_kernel<J_>), grid, dim3(1024), 0, s, (const u32 *)AB,
+                                                (const u32 *)nnan, rows, n, targets, tbegin, m, out, first));
+        }
+        SD_HIP(hipGetLastError());
+    }
+    return SD_OK;
+}
+
 }  // namespace sd

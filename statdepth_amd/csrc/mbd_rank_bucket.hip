@@ -36,6 +36,7 @@
 namespace sd {
 
 constexpr u32 RB_AB_SPECIAL = 0xFFFFFFFFu;     // same encodings as mbd_rank_ab.hip
+constexpr int RB_MEDIUM_MAXN = 24576;          // rank_medium_image_kernel: two blocks of <= 12 288 curves (registers)
 // RB_SMALL_E > 0 builds the kernels with at most that many keys per thread for 64 VGPRs and launches two workgroups
 // (two rows) per CU.  Measured (n = 600..4096, T = 1000): no faster than one workgroup per CU -- the kernel is bound
 // by VALU + LDS throughput, not by latency or barrier stalls -- so it is off.
@@ -1056,6 +1057,212 @@ int launch_rank_finalize(const u64 *partial, int G, int p32, const u32 *AB, cons
     return SD_OK;
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// M: pair image of rows of 16 384 < n <= 2 * 1024 * E curves (the "medium" sizes a 2- or 3-GPU time-sharded step sees:
+// n = N * 10^4), as two column blocks through ONE workgroup.  Ranks are additive over column blocks: per row each block
+// in turn is histogrammed, prefix-summed and scattered exactly as in rank_external_kernel, and EVERY key of the row --
+// the block's own and the other block's -- looks up its bucket there: B += base + #(y < x), A += n_valid - base -
+// #(y <= x) (a key meets itself in its own block: `<=` keeps it out of A, `<` out of B).  Two builds of n / 2 keys and
+// two look-ups per key cost about what one row of the bucket kernel costs per key, against three passes over global
+// memory on the large-n route.  Output as the bucket kernel's image mode (B | A << 16, 0xFFFFFFFF for NaN; counts
+// < 2^15), folded by the same rank_accumulate / finalize kernels.
+// ---------------------------------------------------------------------------------------------------
+template <int NT, int E, int LNB>
+__global__ __launch_bounds__(NT) void rank_medium_image_kernel(const double *__restrict__ Y, i64 n64, i64 row0, i64 rows,
+                                                               u32 *__restrict__ AB, u32 *__restrict__ nnan_img) {
+    using C = RBCfg<NT, E, LNB, 3>;
+    constexpr int NB = C::NB, NW = C::NW, QW = C::QW;
+    extern __shared__ double Sm[];
+    const int n = (int)n64;
+    constexpr int n0 = E * NT;                                        // block 0: curves [0, n0); block 1: [n0, n)
+    const int n1 = n - n0;
+    double *red = Sm;                                                 // [2][NW][2] min/max partials
+    u32 *wtot = reinterpret_cast<u32 *>(red + 4 * NW);                // [NW]
+    u32 *H = reinterpret_cast<u32 *>(Sm + C::HDR / 8);                // NB packed u16 counters, then bases
+    double *S = reinterpret_cast<double *>(H + NB / 2 + 4);           // keys in bucket order
+    const unsigned short *H16 = reinterpret_cast<const unsigned short *>(H);
+    const int t0 = threadIdx.x;
+    const double INF = __builtin_huge_val();
+    const double QNAN = __builtin_nan("");
+    const int DUMMY = C::dummy_pos(n0);
+    int t = t0;
+    {
+        uint4 *Hq = reinterpret_cast<uint4 *>(H);
+#pragma unroll
+        for (int i = 0; i < QW; ++i) Hq[i * NT + t] = make_uint4(0, 0, 0, 0);
+        if (t < 4) H[NB / 2 + t] = 0;
+    }
+    int par = 0;
+    for (i64 r = blockIdx.x; r < rows; r += gridDim.x) {
+        t = t0;
+        asm volatile("" : "+v"(t));                                   // per-row opaque thread id (see rank_bucket_kernel)
+        const int lane = t & 63;
+        const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+        double k0[E], k1[E];
+        {
+            const double *rp = Y + (row0 + r) * n + t;
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                k0[e] = rp[e * NT];
+                k1[e] = (t + e * NT < n1) ? rp[n0 + e * NT] : QNAN;
+            }
+        }
+        u32 *img = AB + r * n + t;                                    // B | A << 16: block 0's share is parked here, block 1's added
+        u32 nn_tot = 0;
+#pragma unroll
+        for (int jb = 0; jb < 2; ++jb) {
+            const double(&kk)[E] = jb ? k1 : k0;
+            const int nblk = jb ? n1 : n0;
+            // ---- (0) range of the block ----
+            double mn = INF, mx = -INF;
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                mn = rb_mm<false>(mn, kk[e]);
+                mx = rb_mm<true>(mx, kk[e]);
+            }
+            mn = rb_wave_allreduce<false>(mn);
+            mx = rb_wave_allreduce<true>(mx);
+            double *redp = red + par * 2 * NW;
+            if (lane == 63) { redp[2 * wave] = mn; redp[2 * wave + 1] = mx; }
+            par ^= 1;
+            __syncthreads();                                          // barrier 1
+            double lo, hi;
+            {
+                const double2 p = reinterpret_cast<const double2 *>(redp)[lane & 15];
+                lo = rb_readlane_f64(rb_row_allreduce<false>(p.x), 0);
+                hi = rb_readlane_f64(rb_row_allreduce<true>(p.y), 0);
+            }
+            double scale = (double)NB / (hi - lo);
+            // equal values, an infinity in the range, a range too small or too large: everything into one bucket
+            if (!((hi > lo) && (scale < INF) && (lo > -INF) && (hi < INF))) scale = 0.0;
+            auto bucket_of = [&](double x) {
+                double u = (x - lo) * scale;
+                u = u > 0.0 ? u : 0.0;                                // below the range, and NaN (0 * inf) -> 0
+                u = u < (double)(NB - 1) ? u : (double)(NB - 1);
+                return (u32)u;
+            };
+            // ---- (1) histogram ----
+            u32 bs[E];
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const double x = kk[e];
+                u32 b = bucket_of(x);
+                b = (x == x) ? b : (u32)(NB + 2);
+                const u32 sh = (b & 1u) * 16u;
+                const u32 old = atomicAdd(&H[b >> 1], 1u << sh);
+                bs[e] = b | (((old >> sh) & 0xFFFFu) << 16);
+            }
+            __syncthreads();                                          // barrier 2
+            // ---- (2) exclusive prefix sum ----
+            {
+                uint4 *Hq = reinterpret_cast<uint4 *>(H) + wave * (64 * QW);
+                uint4 hq[QW];
+                u32 runq[QW], inclq[QW], offq[QW], wsum = 0;
+#pragma unroll
+                for (int i = 0; i < QW; ++i) {
+                    hq[i] = Hq[i * 64 + lane];
+                    const u32 lo16 = (hq[i].x & 0xFFFFu) + (hq[i].y & 0xFFFFu) + (hq[i].z & 0xFFFFu) + (hq[i].w & 0xFFFFu);
+                    const u32 hi16 = (hq[i].x >> 16) + (hq[i].y >> 16) + (hq[i].z >> 16) + (hq[i].w >> 16);
+                    runq[i] = lo16 + hi16;
+                    inclq[i] = rb_wave_incl_scan(runq[i]);
+                    offq[i] = wsum;
+                    wsum += rb_readlane(inclq[i], 63);
+                }
+                if (lane == 63) wtot[wave] = wsum;
+                __syncthreads();                                      // barrier 3
+                const u32 wscan = rb_row_incl_scan(wtot[lane & 15]);
+                const u32 woff = wave ? rb_readlane(wscan, wave - 1) : 0u;
+#pragma unroll
+                for (int i = 0; i < QW; ++i) {
+                    u32 base = woff + offq[i] + inclq[i] - runq[i];
+                    uint4 o;
+                    o.x = base | ((base + (hq[i].x & 0xFFFFu)) << 16);
+                    base += (hq[i].x & 0xFFFFu) + (hq[i].x >> 16);
+                    o.y = base | ((base + (hq[i].y & 0xFFFFu)) << 16);
+                    base += (hq[i].y & 0xFFFFu) + (hq[i].y >> 16);
+                    o.z = base | ((base + (hq[i].z & 0xFFFFu)) << 16);
+                    base += (hq[i].z & 0xFFFFu) + (hq[i].z >> 16);
+                    o.w = base | ((base + (hq[i].w & 0xFFFFu)) << 16);
+                    base += (hq[i].w & 0xFFFFu) + (hq[i].w >> 16);
+                    Hq[i * 64 + lane] = o;
+                    if (i == QW - 1 && t == NT - 1) H[NB / 2] = base; // number of non-NaN keys of the block
+                }
+            }
+            __syncthreads();                                          // barrier 4
+            // ---- (3) scatter ----
+            const u32 nv = H[NB / 2];
+            nn_tot += (u32)nblk - nv;                                 // pad slots beyond the block are NaN too: not counted in nblk
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const u32 b = bs[e] & 0xFFFFu, slot = bs[e] >> 16;
+                const u32 base = H16[b];
+                S[(b < (u32)NB) ? base + slot : (u32)DUMMY] = kk[e];
+            }
+            __syncthreads();                                          // barrier 5
+            // ---- (4) every key of the row against the members of its bucket in this block ----
+            auto lookup = [&](double x, u32 &c) {
+                if (x == x) {
+                    const u32 b = bucket_of(x);
+                    const u32 base = H16[b], end = H16[b + 1];
+                    u32 less = 0, le = 0;
+#pragma unroll 1
+                    for (u32 j = base; j < end; ++j) {
+                        const double y = S[j];
+                        less += (y < x) ? 1u : 0u;
+                        le += (y <= x) ? 1u : 0u;
+                    }
+                    c += (base + less) | ((nv - base - le) << 16);
+                }
+            };
+            // (the counts of the first block wait in the image itself, not in 2 E registers: this thread's own words)
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                u32 ca = 0, cb = 0;
+                lookup(k0[e], ca);
+                lookup(k1[e], cb);
+                if (jb == 0) {
+                    img[e * NT] = ca;
+                    if (t + e * NT < n1) img[n0 + e * NT] = cb;
+                } else {
+                    img[e * NT] = (k0[e] == k0[e]) ? img[e * NT] + ca : RB_AB_SPECIAL;
+                    if (t + e * NT < n1) img[n0 + e * NT] = (k1[e] == k1[e]) ? img[n0 + e * NT] + cb : RB_AB_SPECIAL;
+                }
+            }
+            __syncthreads();                                          // barrier 6: S and the bases have been read
+            {
+                uint4 *Hq = reinterpret_cast<uint4 *>(H) + wave * (64 * QW);
+#pragma unroll
+                for (int i = 0; i < QW; ++i) Hq[i * 64 + lane] = make_uint4(0, 0, 0, 0);
+            }
+        }
+        if (t == 0) nnan_img[r] = nn_tot;
+    }
+}
+
+// medium sizes (16 384 < n <= 32 768 where the registers allow): pair image through two column blocks per workgroup
+bool rank_medium_supported(i64 n) { return n > 16384 && n <= RB_MEDIUM_MAXN; }
+int launch_rank_medium_image(const double *Y, i64 n, i64 row0, i64 rows, u32 *AB, u32 *nnan, hipStream_t s) {
+    if (!rank_medium_supported(n)) return fail(SD_ERR_UNSUPPORTED, "medium image kernel covers 16384 < n <= %d", RB_MEDIUM_MAXN);
+    const int cus = rb_cus();
+    const int G = (int)(rows < cus ? rows : cus);
+    const int E = (int)((n + 2047) / 2048);
+#define RB_MD(E_, L_)                                                                                               \
+    case E_: {                                                                                                       \
+        using C = RBCfg<1024, E_, L_, 3>;                                                                            \
+        const size_t lds = C::lds_bytes(E_ * 1024);                                                                  \
+        auto kf = rank_medium_image_kernel<1024, E_, L_>;                                                            \
+        SD_HIP(hipFuncSetAttribute((const void *)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));        \
+        hipLaunchKernelGGL(kf, dim3(G), dim3(1024), lds, s, Y, n, row0, rows, AB, nnan);                             \
+    } break;
+    switch (E) {
+        RB_MD(9, 14) RB_MD(10, 14) RB_MD(11, 14) RB_MD(12, 14)
+        default: return fail(SD_ERR_UNSUPPORTED, "medium image kernel: no instantiation for n=%lld", (long long)n);
+    }
+#undef RB_MD
+    SD_HIP(hipGetLastError());
+    return SD_OK;
+}
 
 // ---- external targets through the bucket structure ----
 bool mbd_rank_external_supported(i64 T, i64 n, i64 m, int J) {

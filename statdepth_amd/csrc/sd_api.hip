@@ -161,7 +161,8 @@ size_t sd_mbd_workspace_bytes(int64_t T, int64_t n, int64_t st, int64_t sn, int6
     b += align_up((size_t)T * 4, 256);   // nan_cnt
     int a = resolve_mbd_algo(algo, T, n, m, J);
     if (a == SD_MBD_RANK || algo == SD_MBD_AUTO)
-        b += align_up(mbd_rank_workspace_bytes(T, n, J) + mbd_rank_big_workspace_bytes(T, n, J), 256) + 256;
+        b += align_up(mbd_rank_workspace_bytes(T, n, J) + mbd_rank_big_workspace_bytes(T, n, J) +
+                      mbd_rank_medium_workspace_bytes(T, n, J), 256) + 256;
     return b + 1024;
 }
 
@@ -187,6 +188,12 @@ static int mbd_counts_impl(const double *X, int64_t T, int64_t n, int64_t st, in
         Y = Yw;
     }
     int a = resolve_mbd_algo(algo, T, n, m, J);
+    if (a == SD_MBD_RANK && mbd_rank_medium_supported(T, n, J)) {
+        size_t need = mbd_rank_medium_workspace_bytes(T, n, J);
+        void *rws = cv.take(need);
+        if (!rws) return fail(SD_ERR_WORKSPACE, "workspace too small for the medium rank route");
+        return launch_mbd_rank_medium(Y, T, n, targets, tbegin, m, J, (u64 *)out, rws, need, s);
+    }
     if (a == SD_MBD_RANK && mbd_rank_big_supported(T, n, J)) {
         size_t need = mbd_rank_big_workspace_bytes(T, n, J);
         void *rws = cv.take(need);
