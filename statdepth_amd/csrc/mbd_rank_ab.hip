@@ -528,14 +528,14 @@ int launch_mbd_rank(const double *Y, i64 T, i64 n, const i64 *targets, i64 tbegi
     return SD_OK;
 }
 
-// 16 384 < n <= 24 576: pair image by rank_medium_image_kernel (two column blocks per workgroup, mbd_rank_bucket.hip),
+// 16 384 < n <= 40 960: pair image by rank_medium_image_kernel (2 or 3 column blocks per workgroup, mbd_rank_bucket.hip),
 // folded by the same accumulate kernels as the bucket kernel's image mode.
 bool rank_medium_supported(i64 n);
 int launch_rank_medium_image(const double *Y, i64 n, i64 row0, i64 rows, u32 *AB, u32 *nnan, hipStream_t s);
 
 bool mbd_rank_medium_supported(i64 T, i64 n, int J) {
-    (void)T;
-    return rank_medium_supported(n) && J >= 2 && J <= JMAX && xswitch("SD_BIG_NOMEDIUM") != 1;
+    // one workgroup per row: with few rows the large-n route, which spreads a row over several workgroups, fills the chip better
+    return rank_medium_supported(n) && T >= 96 && J >= 2 && J <= JMAX && xswitch("SD_BIG_NOMEDIUM") != 1;
 }
 
 size_t mbd_rank_medium_workspace_bytes(i64 T, i64 n, int J) {
@@ -546,7 +546,7 @@ size_t mbd_rank_medium_workspace_bytes(i64 T, i64 n, int J) {
 
 int launch_mbd_rank_medium(const double *Y, i64 T, i64 n, const i64 *targets, i64 tbegin, i64 m, int J, u64 *out, void *ws,
                            size_t ws_bytes, hipStream_t s) {
-    if (!mbd_rank_medium_supported(T, n, J)) return fail(SD_ERR_UNSUPPORTED, "medium rank route covers 16384 < n <= 24576");
+    if (!mbd_rank_medium_supported(T, n, J)) return fail(SD_ERR_UNSUPPORTED, "medium rank route covers 16384 < n <= 40960 with T >= 96");
     const i64 rpb = ab_rows_per_batch(T, n);
     Carver cv(ws, ws_bytes);
     u32 *AB = (u32 *)cv.take((size_t)rpb * n * 4);

@@ -36,7 +36,7 @@
 namespace sd {
 
 constexpr u32 RB_AB_SPECIAL = 0xFFFFFFFFu;     // same encodings as mbd_rank_ab.hip
-constexpr int RB_MEDIUM_MAXN = 24576;          // rank_medium_image_kernel: two blocks of <= 12 288 curves (registers)
+constexpr int RB_MEDIUM_MAXN = 40960;          // rank_medium_image_kernel: 2 or 3 blocks (measured: 4 blocks lose to the large-n route)
 // RB_SMALL_E > 0 builds the kernels with at most that many keys per thread for 64 VGPRs and launches two workgroups
 // (two rows) per CU.  Measured (n = 600..4096, T = 1000): no faster than one workgroup per CU -- the kernel is bound
 // by VALU + LDS throughput, not by latency or barrier stalls -- so it is off.
@@ -1059,24 +1059,24 @@ int launch_rank_finalize(const u64 *partial, int G, int p32, const u32 *AB, cons
 
 
 // ---------------------------------------------------------------------------------------------------
-// M: pair image of rows of 16 384 < n <= 2 * 1024 * E curves (the "medium" sizes a 2- or 3-GPU time-sharded step sees:
-// n = N * 10^4), as two column blocks through ONE workgroup.  Ranks are additive over column blocks: per row each block
-// in turn is histogrammed, prefix-summed and scattered exactly as in rank_external_kernel, and EVERY key of the row --
-// the block's own and the other block's -- looks up its bucket there: B += base + #(y < x), A += n_valid - base -
-// #(y <= x) (a key meets itself in its own block: `<=` keeps it out of A, `<` out of B).  Two builds of n / 2 keys and
-// two look-ups per key cost about what one row of the bucket kernel costs per key, against three passes over global
-// memory on the large-n route.  Output as the bucket kernel's image mode (B | A << 16, 0xFFFFFFFF for NaN; counts
-// < 2^15), folded by the same rank_accumulate / finalize kernels.
+// M: pair image of rows of 16 384 < n <= 40 960 curves (the "medium" sizes a 2- to 4-GPU time-sharded step sees:
+// n = N * 10^4) as 2 or 3 column blocks through ONE workgroup.  Ranks are additive over column blocks: per row each
+// block in turn is histogrammed, prefix-summed and scattered exactly as in rank_external_kernel, and EVERY key of the
+// row -- the block's own (still in registers) and the other blocks' (read again: the row sits in L2) -- looks up its
+// bucket there: B += base + #(y < x), A += n_valid - base - #(y <= x) (a key meets itself in its own block: `<=` keeps
+// it out of A, `<` out of B).  The running counts wait in the image itself (this thread's own words).  One build and
+// NBLK look-ups per key: about the bucket kernel's cost per key at two blocks, against three passes over global memory
+// on the large-n route.  Output as the bucket kernel's image mode (B | A << 16, 0xFFFFFFFF for NaN; counts < 2^16),
+// folded by the same rank_accumulate kernels.
 // ---------------------------------------------------------------------------------------------------
 template <int NT, int E, int LNB>
-__global__ __launch_bounds__(NT) void rank_medium_image_kernel(const double *__restrict__ Y, i64 n64, i64 row0, i64 rows,
+__global__ __launch_bounds__(NT) void rank_medium_image_kernel(const double *__restrict__ Y, i64 n64, i64 row0, i64 rows, int nblk,
                                                                u32 *__restrict__ AB, u32 *__restrict__ nnan_img) {
     using C = RBCfg<NT, E, LNB, 3>;
     constexpr int NB = C::NB, NW = C::NW, QW = C::QW;
     extern __shared__ double Sm[];
     const int n = (int)n64;
-    constexpr int n0 = E * NT;                                        // block 0: curves [0, n0); block 1: [n0, n)
-    const int n1 = n - n0;
+    constexpr int BS = E * NT;                                        // block j: curves [j BS, min((j + 1) BS, n))
     double *red = Sm;                                                 // [2][NW][2] min/max partials
     u32 *wtot = reinterpret_cast<u32 *>(red + 4 * NW);                // [NW]
     u32 *H = reinterpret_cast<u32 *>(Sm + C::HDR / 8);                // NB packed u16 counters, then bases
@@ -1085,7 +1085,7 @@ __global__ __launch_bounds__(NT) void rank_medium_image_kernel(const double *__r
     const int t0 = threadIdx.x;
     const double INF = __builtin_huge_val();
     const double QNAN = __builtin_nan("");
-    const int DUMMY = C::dummy_pos(n0);
+    const int DUMMY = C::dummy_pos(BS);
     int t = t0;
     {
         uint4 *Hq = reinterpret_cast<uint4 *>(H);
@@ -1099,21 +1099,15 @@ __global__ __launch_bounds__(NT) void rank_medium_image_kernel(const double *__r
         asm volatile("" : "+v"(t));                                   // per-row opaque thread id (see rank_bucket_kernel)
         const int lane = t & 63;
         const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-        double k0[E], k1[E];
-        {
-            const double *rp = Y + (row0 + r) * n + t;
-#pragma unroll
-            for (int e = 0; e < E; ++e) {
-                k0[e] = rp[e * NT];
-                k1[e] = (t + e * NT < n1) ? rp[n0 + e * NT] : QNAN;
-            }
-        }
-        u32 *img = AB + r * n + t;                                    // B | A << 16: block 0's share is parked here, block 1's added
+        const double *row = Y + (row0 + r) * n;
+        u32 *img = AB + r * n;                                        // B | A << 16 so far, per key
         u32 nn_tot = 0;
+        for (int jb = 0; jb < nblk; ++jb) {
+            const int boff = jb * BS;
+            const int bsz = n - boff < BS ? n - boff : BS;
+            double kk[E];
 #pragma unroll
-        for (int jb = 0; jb < 2; ++jb) {
-            const double(&kk)[E] = jb ? k1 : k0;
-            const int nblk = jb ? n1 : n0;
+            for (int e = 0; e < E; ++e) kk[e] = (t + e * NT < bsz) ? row[boff + t + e * NT] : QNAN;
             // ---- (0) range of the block ----
             double mn = INF, mx = -INF;
 #pragma unroll
@@ -1192,7 +1186,7 @@ __global__ __launch_bounds__(NT) void rank_medium_image_kernel(const double *__r
             __syncthreads();                                          // barrier 4
             // ---- (3) scatter ----
             const u32 nv = H[NB / 2];
-            nn_tot += (u32)nblk - nv;                                 // pad slots beyond the block are NaN too: not counted in nblk
+            nn_tot += (u32)bsz - nv;                                  // pad slots beyond the block are NaN too: not in bsz
 #pragma unroll
             for (int e = 0; e < E; ++e) {
                 const u32 b = bs[e] & 0xFFFFu, slot = bs[e] >> 16;
@@ -1201,7 +1195,8 @@ __global__ __launch_bounds__(NT) void rank_medium_image_kernel(const double *__r
             }
             __syncthreads();                                          // barrier 5
             // ---- (4) every key of the row against the members of its bucket in this block ----
-            auto lookup = [&](double x, u32 &c) {
+            auto lookup = [&](double x) -> u32 {
+                u32 c = 0;
                 if (x == x) {
                     const u32 b = bucket_of(x);
                     const u32 base = H16[b], end = H16[b + 1];
@@ -1212,21 +1207,23 @@ __global__ __launch_bounds__(NT) void rank_medium_image_kernel(const double *__r
                         less += (y < x) ? 1u : 0u;
                         le += (y <= x) ? 1u : 0u;
                     }
-                    c += (base + less) | ((nv - base - le) << 16);
+                    c = (base + less) | ((nv - base - le) << 16);
                 }
+                return c;
             };
-            // (the counts of the first block wait in the image itself, not in 2 E registers: this thread's own words)
+            const bool first = jb == 0, last = jb == nblk - 1;
+            for (int ib = 0; ib < nblk; ++ib) {                       // block-uniform
+                const int ioff = ib * BS;
+                const int isz = n - ioff < BS ? n - ioff : BS;
 #pragma unroll
-            for (int e = 0; e < E; ++e) {
-                u32 ca = 0, cb = 0;
-                lookup(k0[e], ca);
-                lookup(k1[e], cb);
-                if (jb == 0) {
-                    img[e * NT] = ca;
-                    if (t + e * NT < n1) img[n0 + e * NT] = cb;
-                } else {
-                    img[e * NT] = (k0[e] == k0[e]) ? img[e * NT] + ca : RB_AB_SPECIAL;
-                    if (t + e * NT < n1) img[n0 + e * NT] = (k1[e] == k1[e]) ? img[n0 + e * NT] + cb : RB_AB_SPECIAL;
+                for (int e = 0; e < E; ++e) {
+                    if (t + e * NT < isz) {
+                        const double x = ib == jb ? kk[e] : row[ioff + t + e * NT];
+                        u32 c = lookup(x);
+                        u32 *w = img + ioff + t + e * NT;
+                        if (!first) c += *w;
+                        *w = (last && !(x == x)) ? RB_AB_SPECIAL : c;
+                    }
                 }
             }
             __syncthreads();                                          // barrier 6: S and the bases have been read
@@ -1240,23 +1237,26 @@ __global__ __launch_bounds__(NT) void rank_medium_image_kernel(const double *__r
     }
 }
 
-// medium sizes (16 384 < n <= 32 768 where the registers allow): pair image through two column blocks per workgroup
+// medium sizes: pair image through 2 or 3 column blocks of at most 16 384 curves per workgroup (10^7 keys, host call
+// included: n = 20 000: 0.159 ms against 0.223 on the large-n route; 30 000: 0.208 / 0.228; 40 000: 0.228 / 0.239;
+// 60 000 as four blocks: 0.355 / 0.243 -- not taken)
 bool rank_medium_supported(i64 n) { return n > 16384 && n <= RB_MEDIUM_MAXN; }
 int launch_rank_medium_image(const double *Y, i64 n, i64 row0, i64 rows, u32 *AB, u32 *nnan, hipStream_t s) {
     if (!rank_medium_supported(n)) return fail(SD_ERR_UNSUPPORTED, "medium image kernel covers 16384 < n <= %d", RB_MEDIUM_MAXN);
     const int cus = rb_cus();
     const int G = (int)(rows < cus ? rows : cus);
-    const int E = (int)((n + 2047) / 2048);
+    const int nblk = (int)((n + 16383) / 16384);                                     // fewest blocks ...
+    const int E = (int)((n + (i64)nblk * 1024 - 1) / ((i64)nblk * 1024));             // ... of equal size, whole thousands
 #define RB_MD(E_, L_)                                                                                               \
     case E_: {                                                                                                       \
         using C = RBCfg<1024, E_, L_, 3>;                                                                            \
         const size_t lds = C::lds_bytes(E_ * 1024);                                                                  \
         auto kf = rank_medium_image_kernel<1024, E_, L_>;                                                            \
         SD_HIP(hipFuncSetAttribute((const void *)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));        \
-        hipLaunchKernelGGL(kf, dim3(G), dim3(1024), lds, s, Y, n, row0, rows, AB, nnan);                             \
+        hipLaunchKernelGGL(kf, dim3(G), dim3(1024), lds, s, Y, n, row0, rows, nblk, AB, nnan);                       \
     } break;
     switch (E) {
-        RB_MD(9, 14) RB_MD(10, 14) RB_MD(11, 14) RB_MD(12, 14)
+        RB_MD(9, 14) RB_MD(10, 14) RB_MD(11, 14) RB_MD(12, 14) RB_MD(13, 14) RB_MD(14, 14) RB_MD(15, 14) RB_MD(16, 13)
         default: return fail(SD_ERR_UNSUPPORTED, "medium image kernel: no instantiation for n=%lld", (long long)n);
     }
 #undef RB_MD

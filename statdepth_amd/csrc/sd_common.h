@@ -77,7 +77,7 @@ int launch_mbd_external_rank(const double *Y, i64 T, i64 n, const double *Q, i64
                              size_t ws_bytes, hipStream_t s);
 // K1+K2 rank formulation for n > 16384 (chunked)
 bool mbd_rank_big_supported(i64 T, i64 n, int J);
-// medium sizes (16 384 < n <= 24 576): two column blocks per workgroup, pair image + fold
+// medium sizes (16 384 < n <= 40 960, T >= 96): 2 or 3 column blocks per workgroup, pair image + fold
 bool mbd_rank_medium_supported(i64 T, i64 n, int J);
 size_t mbd_rank_medium_workspace_bytes(i64 T, i64 n, int J);
 int launch_mbd_rank_medium(const double *Y, i64 T, i64 n, const i64 *targets, i64 tbegin, i64 m, int J, u64 *out, void *ws,
