@@ -13,6 +13,8 @@ for c in range(cases):
     n = int(rng.choice([rng.integers(2, 70), rng.integers(70, 1100), rng.integers(1100, 9000), rng.integers(9000, 16385),
                         rng.integers(16385, 45000)]))
     T = int(rng.integers(1, 12))
+    if 16384 < n <= 40960 and rng.random() < 0.7:
+        T = int(rng.integers(96, 104))                        # the medium route (column blocks) takes over from 96 rows on
     kind = rng.choice(["normal", "walk", "ints", "round", "cauchy", "const", "lognormal", "tiny", "huge"])
     X = rng.normal(size=(T, n))
     if kind == "walk": X = X.cumsum(axis=0)
