@@ -1215,16 +1215,21 @@ __global__ __launch_bounds__(NT) void rank_medium_image_kernel(const double *__r
             for (int ib = 0; ib < nblk; ++ib) {                       // block-uniform
                 const int ioff = ib * BS;
                 const int isz = n - ioff < BS ? n - ioff : BS;
+                // the other block's keys and the running counts first, all in flight together (one at a time they cost a
+                // trip to L2 per key: 48 us per row of 20 000 instead of 30), then the look-ups, then the stores
+                double xk[E];
+                u32 cw[E];
 #pragma unroll
                 for (int e = 0; e < E; ++e) {
-                    if (t + e * NT < isz) {
-                        const double x = ib == jb ? kk[e] : row[ioff + t + e * NT];
-                        u32 c = lookup(x);
-                        u32 *w = img + ioff + t + e * NT;
-                        if (!first) c += *w;
-                        *w = (last && !(x == x)) ? RB_AB_SPECIAL : c;
-                    }
+                    const bool in = t + e * NT < isz;
+                    xk[e] = ib == jb ? kk[e] : (in ? row[ioff + t + e * NT] : QNAN);
+                    cw[e] = (!first && in) ? img[ioff + t + e * NT] : 0u;
                 }
+#pragma unroll
+                for (int e = 0; e < E; ++e) cw[e] += lookup(xk[e]);
+#pragma unroll
+                for (int e = 0; e < E; ++e)
+                    if (t + e * NT < isz) img[ioff + t + e * NT] = (last && !(xk[e] == xk[e])) ? RB_AB_SPECIAL : cw[e];
             }
             __syncthreads();                                          // barrier 6: S and the bases have been read
             {
