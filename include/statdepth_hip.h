@@ -158,6 +158,15 @@ int sd_above_below(const double *X, int64_t T, int64_t n, int64_t st, int64_t sn
  * (_containment.py:80): a pair counts only if its band contains the target at
  * EVERY timepoint.  out[q] = number of such unordered pairs of other curves.
  * depth = out / C(n,2) on the host.
+ * How the pairs are counted (always the same integers):
+ *   T <= 3 (point clouds as `FunctionalDepth([points.T])`: the L-infinity / box depth), any n: per target one pass over
+ *     the curves into 3^T / 4^T state classes and a class transform -- O(n) per target;
+ *   n <= 131 071: curves that are strictly above or below the target at every timepoint ("clean") pair up exactly when
+ *     their above-masks are complements, so those pairs are counted by grouping masks; pairs with a curve that ties
+ *     with the target or holds NaN are tested one by one (only the targets that have such curves);
+ *   beyond: every pair is tested; calls that would need more than 2e14 pair tests are refused (SD_ERR_UNSUPPORTED).
+ * NaN in the target: out[q] = 0; NaN in another curve: it joins both masks (pandas' skipna min / max).
+ * The workspace holds up to 16 GiB of masks for a batch of targets when n is large (sd_bd_strict_workspace_bytes).
  */
 size_t sd_bd_strict_workspace_bytes(int64_t T, int64_t n, int64_t st, int64_t sn, int64_t m);
 int sd_bd_strict_counts(const double *X, int64_t T, int64_t n, int64_t st, int64_t sn,
