@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Collect the rocprofv3 evidence a round's numbers rest on (GPU box only; writes gpurun_out/<tag>_*):
 
-  kernel stats   rocprofv3 --kernel-trace --stats of bench.py (headline, rotating matrices) and of config 3 on one GPU
+  kernel stats   rocprofv3 --kernel-trace --stats of bench.py (headline, rotating matrices), of config 3 on one GPU, of the
+                 strict path (10 000 x 1 000; 10^6 points in R^3) and of the medium route (20 000 x 500)
   HBM traffic    rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in SEPARATE passes (kernel trace only, no other trace domain),
                  corrected as MI355X_MICROARCH.md prescribes: FETCH_SIZE x 2 on gfx950, calibrated in the same session on
                  sd::nan_count_rows_kernel (bench.py --algo pairwise), which reads the 80 000 000-byte matrix exactly once.
@@ -26,6 +27,12 @@ WORKLOADS = {
               "10000x1000", "bench.py headline: config 2, 4 matrices in rotation (every step streams from HBM)"),
     "config3": ([os.path.join(root, "tools", "time_rank.py"), "100000", "256", "10"], "100000x256",
                 "config 3 on one GPU: 100000 curves x 256 timepoints, large-n route"),
+    "strict": ([os.path.join(root, "tools", "time_strict.py"), "10000", "1000", "walks"], "10000x1000",
+               "strict band depth (relax=False), 10000 random walks x 1000 timepoints, every target"),
+    "linf": ([os.path.join(root, "tools", "time_strict.py"), "1000000", "3", "walks"], "1000000x3",
+             "strict L-infinity depth of 10^6 points in R^3 (state-class kernel)"),
+    "medium": ([os.path.join(root, "tools", "time_rank.py"), "20000", "500", "10"], "20000x500",
+               "medium route: 20000 curves x 500 timepoints through two column blocks per workgroup"),
     "calib": ([os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-extras", "--algo",
                "pairwise", "--rotate", "1"], "10000x1000", "calibration: nan_count_rows_kernel reads 80 000 000 bytes once"),
 }
@@ -78,7 +85,7 @@ def pmc(name):
     return res
 
 
-for name in ("bench", "config3"):
+for name in ("bench", "config3", "strict", "linf", "medium"):
     stats(name)
 calib = pmc("calib")
 for name in ("bench", "config3"):
