@@ -745,8 +745,7 @@ __global__ __launch_bounds__(ST_ML_THREADS) void strict_match_lds_kernel(
         }
     }
     __syncthreads();
-    // How many candidates?  The table takes slots * 0.8 of them (n <= 13 107: always enough); a target with more -- data
-    // built of mirrored curves -- is flagged and its groups are formed in the global-memory table by the kernels below.
+    // How many candidates?  (The table takes 0.6 of its slots per round; see below.)
     int cand = 0;
     for (i64 a0 = 0; a0 < n; a0 += ST_ML_THREADS) {
         const i64 a = a0 + tid;
