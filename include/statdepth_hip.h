@@ -139,12 +139,13 @@ int sd_mbd_subset_counts(const double *X, int64_t T, int64_t n, const int32_t *m
 
 /* The same estimator with the reference's default relax=False (`c // T`, _containment.py:80), J = 2: the number of pairs
  * of the block's OTHER members whose band contains the target at EVERY timepoint, for nb (subset, target) pairs in one
- * launch (one workgroup per pair, the block's masks in LDS).  Arguments as sd_mbd_subset_counts; out: int64[nb].
- * Host: depth = out / C(block size, 2).  Blocks that do not fit the LDS (sd_bd_strict_subset_supported == 0:
- * bs * (2 * ceil(T/32) + 2) * 4 bytes > ~158 KB) are refused with SD_ERR_UNSUPPORTED: evaluate those through
- * sd_bd_strict_counts on the block's columns. */
+ * launch (a workgroup per pair, the block's masks in LDS).  Arguments as sd_mbd_subset_counts; out: int64[nb].
+ * Host: depth = out / C(block size, 2).  Blocks whose masks do not fit the LDS (sd_bd_strict_subset_supported == 0:
+ * bs * (2 * ceil(T/32) + 2) * 4 bytes > ~158 KB) keep them in the workspace instead
+ * (sd_bd_strict_subset_workspace_bytes; 0 when the LDS suffices, ws may then be NULL). */
+size_t sd_bd_strict_subset_workspace_bytes(int64_t T, int64_t nb, int bs);
 int sd_bd_strict_subset_counts(const double *X, int64_t T, int64_t n, const int32_t *members, int64_t nb, int bs,
-                               const int32_t *target, int64_t *out, void *stream);
+                               const int32_t *target, int64_t *out, void *ws, size_t ws_bytes, void *stream);
 int sd_bd_strict_subset_supported(int64_t T, int bs);
 
 /* Finest-granularity form of K1 (tests, diagnostics): AB[(q*T + t)*2 + {0,1}] =

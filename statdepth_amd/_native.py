@@ -42,7 +42,8 @@ SIGNATURES = {
     "sd_mbd_external_counts": (_int, [_vp, _i64, _i64, _vp, _i64, _int, _vp, _vp, _sz, _vp]),
     "sd_mbd_external_workspace_bytes": (_sz, [_i64, _i64, _i64, _int]),
     "sd_mbd_subset_counts": (_int, [_vp, _i64, _i64, _vp, _i64, _int, _vp, _int, _vp, _vp]),
-    "sd_bd_strict_subset_counts": (_int, [_vp, _i64, _i64, _vp, _i64, _int, _vp, _vp, _vp]),
+    "sd_bd_strict_subset_workspace_bytes": (_sz, [_i64, _i64, _int]),
+    "sd_bd_strict_subset_counts": (_int, [_vp, _i64, _i64, _vp, _i64, _int, _vp, _vp, _vp, _sz, _vp]),
     "sd_bd_strict_subset_supported": (_int, [_i64, _int]),
     "sd_bd_strict_external_workspace_bytes": (_sz, [_i64, _i64, _i64]),
     "sd_bd_strict_external_counts": (_int, [_vp, _i64, _i64, _vp, _i64, _vp, _vp, _sz, _vp]),

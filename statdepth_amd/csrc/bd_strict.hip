@@ -955,93 +955,110 @@ __global__ __launch_bounds__(ST_THREADS) void strict_subsets_kernel(
 // host evaluates them one at a time through launch_bd_strict.
 // ---------------------------------------------------------------------------------------------------
 constexpr int ST_SUB_THREADS = 512;
+constexpr int ST_SUB_GRID = 2048;                               // workgroups (and scratch slices) of the large-block form
 static inline size_t strict_subset_lds(i64 T, int bs) { return (size_t)bs * (2 * ((T + 31) / 32) + 1) * 4 + (size_t)bs * 4 + 64; }
 bool bd_strict_subsets_supported(i64 T, int bs) { return strict_subset_lds(T, bs) <= 160 * 1024 - 2048; }
+// blocks whose masks do not fit the LDS keep them in a slice of the workspace (L2-resident: a slice is read bs times)
+size_t bd_strict_subsets_workspace_bytes(i64 T, i64 nb, int bs) {
+    if (bd_strict_subsets_supported(T, bs)) return 0;
+    const i64 g = nb < ST_SUB_GRID ? nb : ST_SUB_GRID;
+    return (size_t)g * bs * (2 * ((T + 31) / 32) + 1) * 4 + 256;
+}
 
+// grid-stride over the (subset, target) pairs; scratch == nullptr: masks in LDS
 __global__ __launch_bounds__(ST_SUB_THREADS) void strict_subset_kernel(const double *__restrict__ Y, i64 T, i64 n,
-                                                                      const int *__restrict__ members, int bs,
-                                                                      const int *__restrict__ target, u64 *__restrict__ out) {
+                                                                      const int *__restrict__ members, i64 nb, int bs,
+                                                                      const int *__restrict__ target, u32 *__restrict__ scratch,
+                                                                      u64 *__restrict__ out) {
     extern __shared__ u32 sm[];
     __shared__ u64 red[ST_SUB_THREADS / 64];
     __shared__ int s_cnt;
     const int W32 = (int)((T + 31) / 32);
     const int RW = 2 * W32 + 1;
     int *ids = reinterpret_cast<int *>(sm);                     // [bs] the block's other members
-    u32 *mk = sm + bs;                                          // [cnt][RW]
-    const i64 k = blockIdx.x;
+    u32 *mk = scratch ? scratch + (size_t)blockIdx.x * bs * RW : sm + bs;     // [cnt][RW]
     const int tid = threadIdx.x;
-    const int tg = target[k];
-    if (tid == 0) {
-        int c = 0;
-        for (int e = 0; e < bs; ++e) {
-            const int col = members[k * bs + e];
-            if (col >= 0 && col != tg) ids[c++] = col;
-        }
-        s_cnt = c;
-    }
-    bool tnan = false;
-    for (i64 t = tid; t < T; t += ST_SUB_THREADS) {
-        const double q = Y[t * n + tg];
-        tnan |= q != q;
-    }
-    const bool anynan = __syncthreads_or(tnan) != 0;            // also publishes ids / s_cnt
-    if (anynan) {                                               // NaN in the target: nothing is contained
-        if (tid == 0) out[k] = 0;
-        return;
-    }
-    const int cnt = s_cnt;
-    for (int e = tid; e < cnt * W32; e += ST_SUB_THREADS) {
-        const int c = e / W32, w = e % W32;
-        const i64 col = ids[c];
-        u32 un = 0, dn = 0;
-        const i64 t0 = (i64)w * 32;
-        const int tl = (int)(T - t0 < 32 ? T - t0 : 32);
-        for (int t = 0; t < tl; ++t) {
-            const double x = Y[(t0 + t) * n + col], q = Y[(t0 + t) * n + tg];
-            const bool isn = x != x;
-            un |= (x > q || isn) ? (1u << t) : 0u;
-            dn |= (x < q || isn) ? (1u << t) : 0u;
-        }
-        mk[c * RW + w] = un;
-        mk[c * RW + W32 + w] = dn;
-    }
-    __syncthreads();
-    u64 good = 0;
-    for (int a = tid; a < cnt; a += ST_SUB_THREADS) {
-        const u32 *ra = mk + a * RW;
-        for (int b = a + 1; b < cnt; ++b) {
-            const u32 *rb = mk + b * RW;
-            u32 bad = 0;
-            for (int w = 0; w < W32 && !bad; w += 4) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (w + j < W32) bad |= (ra[w + j] & rb[w + j]) | (ra[W32 + w + j] & rb[W32 + w + j]);
+    for (i64 k = blockIdx.x; k < nb; k += gridDim.x) {
+        __syncthreads();                                        // the previous pair's ids / masks / sums are done with
+        const int tg = target[k];
+        if (tid == 0) {
+            int c = 0;
+            for (int e = 0; e < bs; ++e) {
+                const int col = members[k * bs + e];
+                if (col >= 0 && col != tg) ids[c++] = col;
             }
-            good += bad == 0;
+            s_cnt = c;
         }
-    }
-    for (int o = 32; o > 0; o >>= 1) good += __shfl_down(good, o);
-    if ((tid & 63) == 0) red[tid >> 6] = good;
-    __syncthreads();
-    if (tid == 0) {
-        u64 tot = 0;
-        for (int j = 0; j < ST_SUB_THREADS / 64; ++j) tot += red[j];
-        out[k] = tot;
+        bool tnan = false;
+        for (i64 t = tid; t < T; t += ST_SUB_THREADS) {
+            const double q = Y[t * n + tg];
+            tnan |= q != q;
+        }
+        const bool anynan = __syncthreads_or(tnan) != 0;        // also publishes ids / s_cnt
+        if (anynan) {                                           // NaN in the target: nothing is contained
+            if (tid == 0) out[k] = 0;
+            continue;
+        }
+        const int cnt = s_cnt;
+        for (int e = tid; e < cnt * W32; e += ST_SUB_THREADS) {
+            const int c = e / W32, w = e % W32;
+            const i64 col = ids[c];
+            u32 un = 0, dn = 0;
+            const i64 t0 = (i64)w * 32;
+            const int tl = (int)(T - t0 < 32 ? T - t0 : 32);
+            for (int t = 0; t < tl; ++t) {
+                const double x = Y[(t0 + t) * n + col], q = Y[(t0 + t) * n + tg];
+                const bool isn = x != x;
+                un |= (x > q || isn) ? (1u << t) : 0u;
+                dn |= (x < q || isn) ? (1u << t) : 0u;
+            }
+            mk[c * RW + w] = un;
+            mk[c * RW + W32 + w] = dn;
+        }
+        __syncthreads();                                        // (global stores of this workgroup are visible to it after the barrier)
+        u64 good = 0;
+        for (int a = tid; a < cnt; a += ST_SUB_THREADS) {
+            const u32 *ra = mk + (size_t)a * RW;
+            for (int b = a + 1; b < cnt; ++b) {
+                const u32 *rb = mk + (size_t)b * RW;
+                u32 bad = 0;
+                for (int w = 0; w < W32 && !bad; w += 4) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (w + j < W32) bad |= (ra[w + j] & rb[w + j]) | (ra[W32 + w + j] & rb[W32 + w + j]);
+                }
+                good += bad == 0;
+            }
+        }
+        for (int o = 32; o > 0; o >>= 1) good += __shfl_down(good, o);
+        if ((tid & 63) == 0) red[tid >> 6] = good;
+        __syncthreads();
+        if (tid == 0) {
+            u64 tot = 0;
+            for (int j = 0; j < ST_SUB_THREADS / 64; ++j) tot += red[j];
+            out[k] = tot;
+        }
     }
 }
 
 int launch_bd_strict_subsets(const double *Y, i64 T, i64 n, const int *members, i64 nb, int bs, const int *target, u64 *out,
-                             hipStream_t s) {
-    if (!bd_strict_subsets_supported(T, bs))
-        return fail(SD_ERR_UNSUPPORTED, "strict subset depth: a block of %d curves x %lld timepoints does not fit the LDS", bs,
-                    (long long)T);
-    const size_t lds = strict_subset_lds(T, bs);
-    SD_HIP(hipFuncSetAttribute((const void *)strict_subset_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    for (i64 k0 = 0; k0 < nb; k0 += 65535 * 16) {
-        const i64 kb = nb - k0 < 65535 * 16 ? nb - k0 : 65535 * 16;
-        hipLaunchKernelGGL(strict_subset_kernel, dim3((unsigned)kb), dim3(ST_SUB_THREADS), lds, s, Y, T, n, members + k0 * bs, bs,
-                           target + k0, out + k0);
+                             void *ws, size_t ws_bytes, hipStream_t s) {
+    const bool in_lds = bd_strict_subsets_supported(T, bs);
+    if ((size_t)bs * 4 + 64 > 160 * 1024 - 2048)
+        return fail(SD_ERR_UNSUPPORTED, "strict subset depth: blocks of %d curves (the member list alone exceeds the LDS)", bs);
+    u32 *scratch = nullptr;
+    if (!in_lds) {
+        const size_t need = bd_strict_subsets_workspace_bytes(T, nb, bs);
+        if (!ws || ws_bytes < need)
+            return fail(SD_ERR_WORKSPACE, "strict subset depth: %zu bytes of workspace for blocks of %d curves x %lld timepoints "
+                        "(sd_bd_strict_subset_workspace_bytes)", need, bs, (long long)T);
+        scratch = (u32 *)(((size_t)ws + 255) / 256 * 256);
     }
+    const size_t lds = in_lds ? strict_subset_lds(T, bs) : (size_t)bs * 4 + 64;
+    SD_HIP(hipFuncSetAttribute((const void *)strict_subset_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const i64 g = in_lds ? (nb < 65535 * 16 ? nb : 65535 * 16) : (nb < ST_SUB_GRID ? nb : ST_SUB_GRID);
+    hipLaunchKernelGGL(strict_subset_kernel, dim3((unsigned)g), dim3(ST_SUB_THREADS), lds, s, Y, T, n, members, nb, bs, target, scratch,
+                       out);
     SD_HIP(hipGetLastError());
     return SD_OK;
 }

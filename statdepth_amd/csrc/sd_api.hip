@@ -384,14 +384,20 @@ int sd_bd_strict_external_counts(const double *X, int64_t T, int64_t n, const do
     return launch_bd_strict_external(X, T, n, Q, m, (u64 *)out, ws, ws_bytes, (hipStream_t)stream);
 }
 
+size_t sd_bd_strict_subset_workspace_bytes(int64_t T, int64_t nb, int bs) {
+    if (T <= 0 || nb <= 0 || bs <= 0) return 0;
+    const size_t b = bd_strict_subsets_workspace_bytes(T, nb, bs);
+    return b ? b + 512 : 0;
+}
+
 int sd_bd_strict_subset_counts(const double *X, int64_t T, int64_t n, const int32_t *members, int64_t nb, int bs,
-                               const int32_t *target, int64_t *out, void *stream) {
+                               const int32_t *target, int64_t *out, void *ws, size_t ws_bytes, void *stream) {
     if (!X || !members || !target || !out) return fail(SD_ERR_INVALID, "null pointer");
     if (T <= 0 || n <= 0 || nb < 0 || bs <= 0) return fail(SD_ERR_INVALID, "bad shape");
     int rc = check_count_range(1, bs, 2);
     if (rc) return rc;
     if (nb == 0) return SD_OK;
-    return launch_bd_strict_subsets(X, T, n, members, nb, bs, target, (u64 *)out, (hipStream_t)stream);
+    return launch_bd_strict_subsets(X, T, n, members, nb, bs, target, (u64 *)out, ws, ws_bytes, (hipStream_t)stream);
 }
 
 int sd_bd_strict_subset_supported(int64_t T, int bs) { return T > 0 && bs > 0 && bd_strict_subsets_supported(T, bs) ? 1 : 0; }

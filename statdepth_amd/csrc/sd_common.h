@@ -63,8 +63,9 @@ int launch_mbd_subsets(const double *Y, i64 T, i64 n, const int *members, i64 nb
                        u64 *out, hipStream_t s);
 int launch_above_below(const double *Y, i64 T, i64 n, const i64 *targets, i64 m, u32 *AB, hipStream_t s);
 bool bd_strict_subsets_supported(i64 T, int bs);
+size_t bd_strict_subsets_workspace_bytes(i64 T, i64 nb, int bs);
 int launch_bd_strict_subsets(const double *Y, i64 T, i64 n, const int *members, i64 nb, int bs, const int *target, u64 *out,
-                             hipStream_t s);
+                             void *ws, size_t ws_bytes, hipStream_t s);
 // K1+K2 rank formulation
 size_t mbd_rank_workspace_bytes(i64 T, i64 n, int J);
 bool mbd_rank_supported(i64 T, i64 n, int J);

@@ -22,6 +22,9 @@ from ._helper import DepthDegeneracy, _handle_depth_errors
 __all__ = ['_functionaldepth', '_samplefunctionaldepth']
 
 
+# tests switch this off to compare the one-launch strict estimator with the block-by-block evaluation
+_BATCH_STRICT_BLOCKS = True
+
 def _positions(df: pd.DataFrame, labels) -> np.ndarray:
     """Column positions of `labels` (the reference addresses targets by label, :232)."""
     pos = df.columns.get_indexer(list(labels))
@@ -188,9 +191,9 @@ def _samplefunctionaldepth(data: List[pd.DataFrame], K: int, to_compute: Union[l
     if cdef == 'r2_enum':
         raise NotImplementedError
 
-    # every (target, block) pair in one launch: relax=True always; the reference's default relax=False for J = 2 when a
-    # block's masks fit the LDS (they do unless n / K runs into the thousands)
-    batched = cdef == 'r2' and (relax or (J == 2 and engine.bd_strict_subset_supported(df.shape[0], ss + 1)))
+    # every (target, block) pair in one launch: relax=True always; the reference's default relax=False for J = 2 (the
+    # blocks' masks in LDS, or in the workspace when n / K runs into the thousands)
+    batched = cdef == 'r2' and (relax or (J == 2 and _BATCH_STRICT_BLOCKS))
     blocks, block_targets = [], []           # column positions (in data[0]) of every block, in draw order
     full = data[0]
     for col in orig.columns:

@@ -245,9 +245,11 @@ def bd_strict_subset_counts(X, members, targets, device=None):
     if nb == 0:
         return out.cpu().numpy()
     md, td = t.from_numpy(mem).to(dev), t.from_numpy(tg).to(dev)
+    wsb = int(lib.sd_bd_strict_subset_workspace_bytes(T, nb, bs))
+    ws = t.empty(max(wsb, 8), dtype=t.uint8, device=dev)
     with t.cuda.device(dev):
         check(lib.sd_bd_strict_subset_counts(Xd.data_ptr(), T, n, md.data_ptr(), nb, bs, td.data_ptr(), out.data_ptr(),
-                                         _stream_ptr(dev)))
+                                         ws.data_ptr(), wsb, _stream_ptr(dev)))
     return out.cpu().numpy()
 
 
