@@ -480,9 +480,8 @@ __global__ __launch_bounds__(BK_NT) void bucket_packed_kernel(i64 n, int NB, con
     }
     __syncthreads();
     const u32 base = s_basecnt;
-    const u32 nreal = (u32)n - nnanrow[rb];
     for (int j = t; j < cnt; j += NT) {
-        ab.B[rb * n + bidx[slot0 + j]] = base + R[j];               // distinct keys: A = nreal - 1 - B
+        ab.B[rb * n + bidx[slot0 + j]] = base + R[j];               // distinct keys: A = (n - NaNs of the row) - 1 - B
     }
 }
 #endif  // SD_CROSSCHECK
