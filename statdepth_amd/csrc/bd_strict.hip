@@ -15,7 +15,7 @@
 //   J = 2, T <= 3, any n      strict_class_kernel: the masks ARE classes (4^T or 3^T of them); per target one pass over
 //                             the curves and a class transform.  The L-infinity depth of point clouds.
 //   J = 2, n <= 131 071       per batch of targets: masks (strict_masks_rank_kernel from the bucket kernel's rank image
-//                             for n <= 16 384, else strict_masks2_kernel from the values) -> digests of the canonical
+//                             for n <= 32 767, else strict_masks2_kernel from the values) -> digests of the canonical
 //                             masks (strict_hash_kernel) -> pairs of CLEAN curves counted by grouping complementary
 //                             masks (strict_match_lds_kernel; global-memory table behind it) -> pairs with a DIRTY
 //                             curve (tie / NaN) tested by strict_pairs2_kernel, for the targets that have any.
@@ -31,7 +31,9 @@
 namespace sd {
 
 int launch_rank_bucket_image(const double *Y, i64 n, i64 row0, i64 rows, u32 *AB, u32 *nnan, hipStream_t s);   // mbd_rank_bucket.hip
-constexpr i64 ST_RANK_MAXN = 16384;          // what the bucket kernel covers
+int launch_rank_medium_image(const double *Y, i64 n, i64 row0, i64 rows, u32 *AB, u32 *nnan, hipStream_t s);   // ... its two-block form
+constexpr i64 ST_RANK_MAXN = 32767;          // ranks below 2^15 (two per register in the mask kernel); images: bucket kernel up to
+                                             // 16 384 curves, its column-block form beyond
 
 constexpr int ST_THREADS = 256;
 constexpr int ST_WREG = 16;          // mask words kept in registers (T <= 1024)
@@ -269,7 +271,7 @@ __global__ __launch_bounds__(ST_THREADS) void strict_masks2_kernel(
     }
 }
 
-// The same masks from INTEGER ranks (n <= 16 384).  The bucket kernel's image mode (mbd_rank_bucket.hip) turns the
+// The same masks from INTEGER ranks (n <= 32 767).  The bucket kernel's image mode (mbd_rank_bucket.hip) turns the
 // matrix into R[t][i] = B | A << 16 with B = number of curves strictly below curve i at t (0xFFFFFFFF: NaN): B is order-
 // and tie-preserving (x_i > x_q <=> B_i > B_q, equal values share B), costs one pass of the headline kernel (0.07 ms at
 // 10 000 x 1 000), and makes the mask kernel's compares 32-bit (full rate; the fp64 ones run at half) on half the
@@ -1304,7 +1306,9 @@ static int launch_bd_strict_impl(const double *Y, i64 T, i64 n, const i64 *targe
         // the image launcher takes at most 2048 rows per workgroup
         const i64 step = 2048 * 64;
         for (i64 r0 = 0; r0 < T; r0 += step) {
-            int rc = launch_rank_bucket_image(Y, n, r0, T - r0 < step ? T - r0 : step, R + r0 * n, rnan + r0, s);
+            const i64 rows = T - r0 < step ? T - r0 : step;
+            int rc = n <= 16384 ? launch_rank_bucket_image(Y, n, r0, rows, R + r0 * n, rnan + r0, s)
+                                : launch_rank_medium_image(Y, n, r0, rows, R + r0 * n, rnan + r0, s);
             if (rc) return rc;
         }
         SD_HIP(hipMemsetAsync(tiemask, 0, (size_t)((T + 31) / 32) * 4, s));
