@@ -37,6 +37,14 @@ def _pointwisedepth(data: pd.DataFrame, to_compute: Union[list, pd.Index] = None
         P = data.to_numpy(dtype=np.float64)
         depths = engine.l1_depth(P, _row_positions(data, to_compute), device=device)
         return pd.Series(index=to_compute, data=depths)          # (:150)
+    elif containment in ('linf', 'linf_relax'):
+        # An extension (the reference knows no such string and raises ValueError, :63-64): the L-infinity / box
+        # containment SURVEY 8 P4 spells out with reference semantics -- the band depth of the points read as curves over
+        # their coordinates, FunctionalDepth([data.T]).  'linf': the share of pairs of other points whose bounding box
+        # contains the point (relax=False); 'linf_relax': the mean over the coordinates (relax=True).
+        from ._functional import _univariate_depths
+        depths = _univariate_depths(data.T, list(to_compute), 2, containment == 'linf_relax', device=device)
+        return pd.Series(index=to_compute, data=depths)
     elif containment in ('mahalanobis', 'oja'):
         raise NotImplementedError(f'{containment} depth is outside the band-depth hot path this engine covers')
     else:
