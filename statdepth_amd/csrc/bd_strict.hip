@@ -747,9 +747,11 @@ __global__ __launch_bounds__(ST_ML_THREADS) void strict_match_lds_kernel(
         }
     }
     __syncthreads();
-    // How many candidates?  (The table takes 0.6 of its slots per round; see below.)
+    // How many candidates?  (The table takes 0.6 of its slots per round; see below.)  Not counted when even all n curves
+    // would fit at a load of 0.8.
     int cand = 0;
-    for (i64 a0 = 0; a0 < n; a0 += ST_ML_THREADS) {
+    const bool must_count = (i64)n * 5 > (i64)slots * 4;
+    for (i64 a0 = 0; a0 < n && must_count; a0 += ST_ML_THREADS) {
         const i64 a = a0 + tid;
         const u64 hf = a < n ? hb[a] : 0;
         bool c = false;
