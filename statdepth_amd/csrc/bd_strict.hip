@@ -634,29 +634,23 @@ __global__ __launch_bounds__(ST_THREADS) void strict_pairs2_kernel(
 // ---------------------------------------------------------------------------------------------------
 // Timepoints at which all curves hold the same value (a common start, say) constrain no pair: cmask has their bits, and
 // the matching treats them as absent (they would otherwise make every curve "tie" and send every target to the pair
-// kernel).  grid = W32 blocks, one per mask word.
+// kernel).
 __global__ __launch_bounds__(ST_THREADS) void strict_const_rows_kernel(const double *__restrict__ Y, i64 T, i64 n,
                                                                       u32 *__restrict__ cmask) {
-    __shared__ int differs;
-    const i64 t0 = (i64)blockIdx.x * 32;
-    u32 word = 0;
-    for (int k = 0; k < 32 && t0 + k < T; ++k) {
-        if (threadIdx.x == 0) differs = 0;
-        __syncthreads();
-        const double *row = Y + (t0 + k) * n;
-        const double first = row[0];
-        for (i64 i0 = 0; i0 < n; i0 += ST_THREADS) {
-            const i64 i = i0 + threadIdx.x;
-            if (i < n && !(row[i] == first)) differs = 1;       // NaN differs from everything
-            __syncthreads();
-            const int d = differs;                               // block-uniform
-            __syncthreads();
-            if (d) break;
+    // grid = T blocks, one per timepoint (cmask zeroed before): a row of equal values sets its bit
+    const i64 t = blockIdx.x;
+    const double *row = Y + t * n;
+    const double first = row[0];
+    bool differs = false;
+    for (i64 i0 = 0; i0 < n; i0 += (i64)ST_THREADS * 8) {       // eight strides between the block-wide checks
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const i64 i = i0 + (i64)u * ST_THREADS + threadIdx.x;
+            if (i < n && !(row[i] == first)) differs = true;     // NaN differs from everything
         }
-        if (!differs) word |= 1u << k;
-        __syncthreads();
+        if (__syncthreads_or(differs)) return;                   // block-uniform
     }
-    if (threadIdx.x == 0) cmask[blockIdx.x] = word;
+    if (threadIdx.x == 0) atomicOr(&cmask[t >> 5], 1u << (t & 31));
 }
 
 // do curves a and rep have the same canonical mask for this target?  Equal HF words (payload, exact flag; sides apart)
@@ -1299,10 +1293,9 @@ static int launch_bd_strict_impl(const double *Y, i64 T, i64 n, const i64 *targe
         if (threads > 4.0e9) return fail(SD_ERR_UNSUPPORTED, "strict J=%d enumeration too large for n=%lld", J, (long long)n);
     }
     if (match) {
-        if (Q)      // an external target does not share a value all of Y's curves share: every timepoint counts
-            SD_HIP(hipMemsetAsync(cmask, 0, (size_t)((T + 31) / 32) * 4, s));
-        else
-            hipLaunchKernelGGL(strict_const_rows_kernel, dim3((unsigned)((T + 31) / 32)), dim3(ST_THREADS), 0, s, Y, T, n, cmask);
+        SD_HIP(hipMemsetAsync(cmask, 0, (size_t)((T + 31) / 32) * 4, s));
+        // (an external target does not share a value all of Y's curves share: every timepoint counts for it)
+        if (!Q) hipLaunchKernelGGL(strict_const_rows_kernel, dim3((unsigned)T), dim3(ST_THREADS), 0, s, Y, T, n, cmask);
     }
     if (rankmasks) {
         // the image launcher takes at most 2048 rows per workgroup
