@@ -271,6 +271,34 @@ def extras_multi_gpu(torch, dist, dev, rank, N, reps=5):
     return out
 
 
+def launch_plan(gpus, argv, env):
+    """How `bench.py --gpus N` gets its ranks.  Under a launcher (WORLD_SIZE set: the driver's `python -m torch.distributed.run
+    ...`) or at N = 1 this process IS a rank.  With N > 1 and no launcher the process becomes a parent that starts N ranks of
+    itself through torch.distributed.run on 127.0.0.1 and relays rank 0's JSON line -- it never imports torch or touches the
+    GPU, so nothing that has initialised HIP is ever exec'ed or re-exec'ed."""
+    world = env.get("WORLD_SIZE")
+    child_args = [a for a in argv if a != "--print-launch"]
+    if gpus <= 1 or world is not None:
+        return {"self_launch": False, "world_size": int(world or 1), "argv": None,
+                "reason": "launched under torch.distributed.run" if world is not None else "single GPU: this process is rank 0"}
+    port = int(env.get("MASTER_PORT", "0")) or (29600 + os.getpid() % 2000)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + child_args
+    return {"self_launch": True, "world_size": gpus, "argv": cmd,
+            "reason": f"--gpus {gpus} without WORLD_SIZE: parent starts {gpus} ranks as child processes (one per GPU, RCCL)"}
+
+
+def self_launch(plan):
+    """Parent side of a self-launched multi-GPU run: children inherit stdout (rank 0 prints the one JSON line), the parent
+    exits with their code.  No GPU call happens in this process."""
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    sys.stdout.flush()
+    return subprocess.run(plan["argv"], env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -294,7 +322,17 @@ def main():
                     help="run the torch.distributed path even at world size 1 (exercises RCCL on one GPU)")
     ap.add_argument("--extras-multi", action="store_true",
                     help="with --force-dist: also run the multi-GPU extras (configs 3 and 5 through the sharded paths) at world size 1")
+    ap.add_argument("--print-launch", action="store_true",
+                    help="print the launch plan (the child command for --gpus N > 1 without a launcher) as JSON and exit; "
+                         "touches no GPU")
     args = ap.parse_args()
+
+    plan = launch_plan(args.gpus, sys.argv[1:], os.environ)
+    if args.print_launch:
+        print(json.dumps(plan))
+        return 0
+    if plan["self_launch"]:
+        return self_launch(plan)
 
     import torch
     import torch.distributed as dist
@@ -305,6 +343,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     use_dist = world > 1 or args.force_dist
+    if torch.cuda.device_count() <= local:
+        raise SystemExit(f"bench.py: rank {rank}: no HIP device {local} on this host ({torch.cuda.device_count()} visible); "
+                         "the hot path has no CPU fallback")
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
@@ -325,7 +366,9 @@ def main():
             os.dup2(keep, 1)
             os.close(keep)
     N = world
-    assert args.gpus == N, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if args.gpus != N:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus}, or "
+                         f"unset WORLD_SIZE and let bench.py start its own ranks")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     lib = _native.require_device()
@@ -476,7 +519,8 @@ def main():
         print(json.dumps(line), flush=True)
     if use_dist:
         dist.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -2,6 +2,7 @@
 the host mirror of the reference's API validates arguments the same way, result objects
 behave like the reference's, and the product fails loudly without a GPU (no CPU fallback)."""
 import os
+import sys
 import re
 
 import numpy as np
@@ -238,3 +239,33 @@ def test_bench_contract_and_committed_evidence():
     for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert key in line["roofline"], key
     assert abs(line["roofline"]["frac"] - line["roofline"]["achieved"] / line["roofline"]["peak"]) < 1e-9
+
+
+def test_bench_self_launch_plan():
+    """`python bench.py --gpus N` (N > 1) without a launcher starts its own ranks from a parent that never touches the GPU;
+    under a launcher (WORLD_SIZE set) or at N = 1 the process is a rank itself.  Dry run only: no rank is started here."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    bench = os.path.join(ROOT, "bench.py")
+
+    def plan(args, **extra):
+        out = subprocess.run([sys.executable, bench] + args + ["--print-launch"], env={**env, **extra}, capture_output=True,
+                             text=True, timeout=120)
+        assert out.returncode == 0, out.stderr
+        return json.loads(out.stdout.strip().splitlines()[-1])
+
+    p = plan(["--gpus", "4", "--steps", "7", "--warmup", "2"])
+    assert p["self_launch"] and p["world_size"] == 4
+    a = p["argv"]
+    assert a[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=4" in a and "--nnodes=1" in a
+    assert a[a.index("--master-addr") + 1] == "127.0.0.1" and a[a.index("--master-port") + 1].isdigit()
+    k = a.index(bench)
+    assert a[k + 1:] == ["--gpus", "4", "--steps", "7", "--warmup", "2"]          # the children run the same command line
+    assert not plan([])["self_launch"] and not plan(["--gpus", "1"])["self_launch"]
+    under = plan(["--gpus", "4"], WORLD_SIZE="4", RANK="0", LOCAL_RANK="0")
+    assert not under["self_launch"] and under["world_size"] == 4
+    # the parent of a self-launched run must not have imported torch (and so cannot have initialised HIP)
+    src = open(bench).read()
+    head = src[:src.index("def main():")]
+    assert "import torch" not in head
