@@ -167,9 +167,12 @@ int sd_above_below(const double *X, int64_t T, int64_t n, int64_t st, int64_t sn
  *     with the target or holds NaN are tested one by one (only the targets that have such curves);
  *   beyond: every pair is tested; calls that would need more than 2e14 pair tests are refused (SD_ERR_UNSUPPORTED).
  * NaN in the target: out[q] = 0; NaN in another curve: it joins both masks (pandas' skipna min / max).
- * The workspace holds up to 16 GiB of masks for a batch of targets when n is large (sd_bd_strict_workspace_bytes).
+ * The workspace holds up to 16 GiB of masks for a batch of targets when n is large (sd_bd_strict_workspace_bytes: the
+ * RECOMMENDED size).  A caller short of memory may pass less, down to sd_bd_strict_min_workspace_bytes (one target per
+ * batch): the launcher sizes its batches to what it is given -- same integers, more launches.
  */
 size_t sd_bd_strict_workspace_bytes(int64_t T, int64_t n, int64_t st, int64_t sn, int64_t m);
+size_t sd_bd_strict_min_workspace_bytes(int64_t T, int64_t n, int64_t st, int64_t sn, int64_t m, int J);
 int sd_bd_strict_counts(const double *X, int64_t T, int64_t n, int64_t st, int64_t sn,
                         const int64_t *targets, int64_t m,
                         int64_t *out, void *ws, size_t ws_bytes, void *stream);

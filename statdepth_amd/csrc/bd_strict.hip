@@ -62,15 +62,38 @@ static i64 strict_batch(i64 T, i64 n, i64 m) {
     return b;
 }
 
-size_t bd_strict_workspace_bytes(i64 T, i64 n, i64 m, int J) {
-    // short series go through the class kernel (launch_bd_strict_classes): a flag, no images
-    if (J == 2 && T <= 3 && xswitch("SD_STRICT_V1") != 1 && xswitch("SD_STRICT_NOCLASS") != 1) return 4096;
-    i64 b = strict_batch(T, n, m);
+// bytes of the mask pipeline's workspace for batches of b targets (the layout launch_bd_strict_impl carves)
+static size_t strict_ws_for_batch(i64 T, i64 n, i64 b) {
     return align_up((size_t)b * n * 2 * strict_words(T) * 8, 256) + align_up((size_t)b * 4, 256) +
            align_up((size_t)b * (strict_table_slots(n) * 16 + 16 + ((n + 63) / 64) * 8), 256) +
            align_up((size_t)((T + 31) / 32) * 4, 256) + align_up((size_t)b * ((T + 31) / 32) * 256, 256) +
            align_up((size_t)b * n * 8, 256) + align_up((size_t)b * n, 256) + align_up((size_t)(b + 1) * 4, 256) +
            (n <= ST_RANK_MAXN ? align_up((size_t)T * n * 4, 256) + 2 * align_up((size_t)T * 4, 256) : 0) + 2560;
+}
+
+// The RECOMMENDED size (batches of strict_batch targets).  The launchers take any workspace that holds a batch of one
+// target and size their batches to what they are given (strict_batch_for_ws), so a caller short of memory may pass less:
+// bd_strict_min_workspace_bytes is the floor.
+size_t bd_strict_workspace_bytes(i64 T, i64 n, i64 m, int J) {
+    // short series go through the class kernel (launch_bd_strict_classes): a flag, no images
+    if (J == 2 && T <= 3 && xswitch("SD_STRICT_V1") != 1 && xswitch("SD_STRICT_NOCLASS") != 1) return 4096;
+    return strict_ws_for_batch(T, n, strict_batch(T, n, m));
+}
+size_t bd_strict_min_workspace_bytes(i64 T, i64 n, i64 m, int J) {
+    if (J == 2 && T <= 3 && xswitch("SD_STRICT_V1") != 1 && xswitch("SD_STRICT_NOCLASS") != 1) return 4096;
+    return strict_ws_for_batch(T, n, 1);
+}
+// largest batch (<= the recommended one) whose layout fits ws_bytes; 0: not even one target fits
+static i64 strict_batch_for_ws(i64 T, i64 n, i64 m, size_t ws_bytes) {
+    i64 hi = strict_batch(T, n, m);
+    if (strict_ws_for_batch(T, n, hi) <= ws_bytes) return hi;
+    if (strict_ws_for_batch(T, n, 1) > ws_bytes) return 0;
+    i64 lo = 1;                                               // fits
+    while (hi - lo > 1) {
+        const i64 mid = lo + (hi - lo) / 2;
+        if (strict_ws_for_batch(T, n, mid) <= ws_bytes) lo = mid; else hi = mid;
+    }
+    return lo;
 }
 
 // masks[b][i][0..W) = UN, masks[b][i][W..2W) = DN
@@ -795,6 +818,10 @@ __global__ __launch_bounds__(ST_ML_THREADS) void strict_match_lds_kernel(
                             const u32 rside = (cur >> 17) & 1u;
                             const u32 old = atomicAdd(&cntl[slot], side ? 0x10000u : 1u);
                             acc += side ? (old & 0xFFFFu) + (rside == 0) : (old >> 16) + (rside == 1);
+                            // the two side counts share one word: a group with more than 65 535 later members on one
+                            // side would carry into the other half -- such a target goes to the global-memory table
+                            // (full 32-bit counters), which recounts ALL its groups
+                            stuck |= (side ? old >> 16 : old & 0xFFFFu) == 0xFFFFu;
                             break;
                         }
                     }
@@ -949,8 +976,8 @@ __global__ __launch_bounds__(ST_THREADS) void strict_subsets_kernel(
 // _functional.py:170-182 calls _univariate_band_depth on n*K small blocks).  One workgroup per pair: the block's masks
 // against its target are built in LDS (u32[members][2 W32 + 1], the + 1 keeps rows on different banks), then every
 // thread walks the pairs (a, b > a) of its members a with an early exit per four words.  Blocks are small (n / K
-// curves), so the whole pair fits the LDS: members * (2 W32 + 1) * 4 + bs * 4 bytes; larger ones are refused and the
-// host evaluates them one at a time through launch_bd_strict.
+// curves), so the whole pair fits the LDS: members * (2 W32 + 1) * 4 + bs * 4 bytes; larger ones keep their masks in a
+// slice of the workspace instead (strict_subset_big_kernel below; refused only when bs * 4 + 64 exceeds the LDS).
 // ---------------------------------------------------------------------------------------------------
 constexpr int ST_SUB_THREADS = 512;
 constexpr int ST_SUB_GRID = 2048;                               // workgroups (and scratch slices) of the large-block form
@@ -1231,7 +1258,7 @@ int launch_bd_strict_external(const double *Y, i64 T, i64 n, const double *Q, i6
     // the kernels exclude "the target itself" from the others by its column index: -1 for every external target
     Carver cv(ws, ws_bytes);
     i64 *none = (i64 *)cv.take((size_t)m * 8);
-    const size_t need = bd_strict_workspace_bytes(T, n, m, 2);
+    const size_t need = cv.rest();                            // everything behind the index block: the batches adapt to it
     void *sws = cv.take(need);
     if (!none || !sws) return fail(SD_ERR_WORKSPACE, "strict-depth workspace too small (sd_bd_strict_external_workspace_bytes)");
     SD_HIP(hipMemsetAsync(none, 0xFF, (size_t)m * 8, s));
@@ -1244,7 +1271,9 @@ static int launch_bd_strict_impl(const double *Y, i64 T, i64 n, const i64 *targe
     if (J == 2 && T <= 3 && xswitch("SD_STRICT_V1") != 1 && xswitch("SD_STRICT_NOCLASS") != 1)
         return launch_bd_strict_classes(Y, T, n, Q ? nullptr : targets, Q, m, out, 1, ws, ws_bytes, s);
     i64 W = strict_words(T);
-    i64 B = strict_batch(T, n, m);
+    const i64 B = strict_batch_for_ws(T, n, m, ws_bytes);     // the recommended batch, or what the caller's workspace holds
+    if (B < 1) return fail(SD_ERR_WORKSPACE, "strict-depth workspace too small: %zu bytes, one target takes %zu "
+                           "(sd_bd_strict_min_workspace_bytes)", ws_bytes, strict_ws_for_batch(T, n, 1));
     Carver cv(ws, ws_bytes);
     u64 *masks = (u64 *)cv.take((size_t)B * n * 2 * W * 8);
     u32 *xnan = (u32 *)cv.take((size_t)B * 4);

@@ -345,6 +345,13 @@ size_t sd_bd_strict_workspace_bytes(int64_t T, int64_t n, int64_t st, int64_t sn
     return sd_bd_strict_j_workspace_bytes(T, n, st, sn, m, 2);
 }
 
+size_t sd_bd_strict_min_workspace_bytes(int64_t T, int64_t n, int64_t st, int64_t sn, int64_t m, int J) {
+    if (T <= 0 || n <= 0) return 0;
+    size_t b = 0;
+    if (!is_time_major_dense(n, st, sn)) b += align_up((size_t)T * n * 8, 256);
+    return b + bd_strict_min_workspace_bytes(T, n, m, J) + 1024;
+}
+
 int sd_bd_strict_j_counts(const double *X, int64_t T, int64_t n, int64_t st, int64_t sn,
                           const int64_t *targets, int64_t m, int J,
                           int64_t *out, void *ws, size_t ws_bytes, void *stream) {
@@ -363,9 +370,10 @@ int sd_bd_strict_j_counts(const double *X, int64_t T, int64_t n, int64_t st, int
         if ((rc = launch_to_time_major(X, T, n, st, sn, Yw, s))) return rc;
         Y = Yw;
     }
-    size_t need = bd_strict_workspace_bytes(T, n, m, J);
+    size_t need = cv.rest();                                   // batches are sized to what the caller passed
     void *sws = cv.take(need);
-    if (!sws) return fail(SD_ERR_WORKSPACE, "workspace too small for the strict-depth masks");
+    if (!sws || need < bd_strict_min_workspace_bytes(T, n, m, J))
+        return fail(SD_ERR_WORKSPACE, "workspace too small for the strict-depth masks (sd_bd_strict_min_workspace_bytes)");
     return launch_bd_strict(Y, T, n, targets, m, J, (u64 *)out, sws, need, s);
 }
 

@@ -79,6 +79,46 @@ def to_device_matrix(X, device=None):
     return DeviceMatrix(t.from_numpy(A.T).to(dev).t())
 
 
+# One grow-only scratch buffer per device, reused by every call (the C ABI takes the workspace as an argument and keeps
+# nothing in it between calls): a repeated call of the same shape pays no allocation and no allocator round trip.  Buffers
+# above _WS_KEEP bytes are handed out once and not kept (strict depth at large n asks for GiBs).
+_WS_KEEP = 2 << 30
+_ws_cache = {}
+
+
+def _ws_key(dev):
+    # per (device, stream): calls on one stream run in order and may share the buffer, calls on two streams may overlap
+    t = torch()
+    idx = dev.index if dev.index is not None else t.cuda.current_device()
+    return (idx, t.cuda.current_stream(dev).cuda_stream)
+
+
+def _workspace(dev, nbytes):
+    t = torch()
+    nbytes = max(int(nbytes), 8)
+    key = _ws_key(dev)
+    buf = _ws_cache.get(key)
+    if buf is not None and buf.numel() >= nbytes:
+        return buf
+    new = t.empty(nbytes, dtype=t.uint8, device=dev)
+    if nbytes <= _WS_KEEP:
+        _ws_cache[key] = new
+    return new
+
+
+def release_workspace():
+    """Drop the cached scratch buffers (they are plain torch tensors; the caching allocator gets them back)."""
+    _ws_cache.clear()
+
+
+def _check_members(mem, tg, n):
+    """Block member / target indices go to the device as they are: refuse what would read outside the data set."""
+    if mem.size and (int(mem.min()) < -1 or int(mem.max()) >= n):
+        raise IndexError("block member index out of range (valid: -1 padding, 0 .. n-1)")
+    if tg is not None and len(tg) and (int(tg.min()) < 0 or int(tg.max()) >= n):
+        raise IndexError("block target index out of range")
+
+
 def _targets_dev(targets, n, dev):
     t = torch()
     if targets is None:
@@ -104,7 +144,7 @@ def mbd_counts(X, targets=None, J=2, algo="auto", device=None, return_tensor=Fal
     if m == 0:
         return out if return_tensor else out.cpu().numpy()
     wsb = lib.sd_mbd_workspace_bytes(M.T, M.n, M.st, M.sn, m, J, a)
-    ws = t.empty(max(int(wsb), 8), dtype=t.uint8, device=dev)
+    ws = _workspace(dev, wsb)
     with t.cuda.device(dev):
         check(lib.sd_mbd_counts(M.tensor.data_ptr(), M.T, M.n, M.st, M.sn, tp, m, J, a,
                             out.data_ptr(), ws.data_ptr(), wsb, _stream_ptr(dev)))
@@ -124,7 +164,7 @@ def mbd_counts_wide(X, targets=None, J=2, algo="auto", device=None):
     out = t.zeros((m, J - 1, 2), dtype=t.int64, device=dev)
     if m:
         wsb = lib.sd_mbd_wide_workspace_bytes(M.T, M.n, M.st, M.sn, m, J, a)
-        ws = t.empty(max(int(wsb), 8), dtype=t.uint8, device=dev)
+        ws = _workspace(dev, wsb)
         with t.cuda.device(dev):
             check(lib.sd_mbd_counts_wide(M.tensor.data_ptr(), M.T, M.n, M.st, M.sn, tp, m, J, a,
                                          out.data_ptr(), ws.data_ptr(), wsb, _stream_ptr(dev)))
@@ -147,7 +187,7 @@ def mbd_counts_range(X, target_begin, m, J=2, algo="auto", device=None, return_t
     if m == 0:
         return out if return_tensor else out.cpu().numpy()
     wsb = lib.sd_mbd_workspace_bytes(M.T, M.n, M.st, M.sn, m, J, a)
-    ws = t.empty(max(int(wsb), 8), dtype=t.uint8, device=dev)
+    ws = _workspace(dev, wsb)
     with t.cuda.device(dev):
         check(lib.sd_mbd_counts_range(M.tensor.data_ptr(), M.T, M.n, M.st, M.sn, int(target_begin), int(m), J, a,
                                   out.data_ptr(), ws.data_ptr(), wsb, _stream_ptr(dev)))
@@ -169,7 +209,7 @@ def mbd_external_counts(X, Q, J=2, device=None):
     m = Qd.shape[1]
     out = t.empty((m, J - 1), dtype=t.int64, device=dev)
     wsb = int(lib.sd_mbd_external_workspace_bytes(T, n, m, J)) + 1024
-    ws = t.empty(wsb, dtype=t.uint8, device=dev)
+    ws = _workspace(dev, wsb)
     with t.cuda.device(dev):
         check(lib.sd_mbd_external_counts(Xd.data_ptr(), T, n, Qd.data_ptr(), m, J, out.data_ptr(), ws.data_ptr(), wsb,
                                      _stream_ptr(dev)))
@@ -191,7 +231,7 @@ def bd_strict_external_counts(X, Q, device=None):
     if m == 0:
         return out.cpu().numpy()
     wsb = int(lib.sd_bd_strict_external_workspace_bytes(T, n, m))
-    ws = t.empty(max(wsb, 8), dtype=t.uint8, device=dev)
+    ws = _workspace(dev, wsb)
     with t.cuda.device(dev):
         check(lib.sd_bd_strict_external_counts(Xd.data_ptr(), T, n, Qd.data_ptr(), m, out.data_ptr(), ws.data_ptr(), wsb,
                                            _stream_ptr(dev)))
@@ -212,6 +252,7 @@ def mbd_subset_counts(X, members, targets, J=2, device=None):
     nb, bs = mem.shape
     if len(tg) != nb:
         raise ValueError("one target per block")
+    _check_members(mem, tg, n)
     out = t.empty((nb, J - 1), dtype=t.int64, device=dev)
     if nb == 0:
         return out.cpu().numpy()
@@ -241,12 +282,13 @@ def bd_strict_subset_counts(X, members, targets, device=None):
     nb, bs = mem.shape
     if len(tg) != nb:
         raise ValueError("one target per block")
+    _check_members(mem, tg, n)
     out = t.empty((nb,), dtype=t.int64, device=dev)
     if nb == 0:
         return out.cpu().numpy()
     md, td = t.from_numpy(mem).to(dev), t.from_numpy(tg).to(dev)
     wsb = int(lib.sd_bd_strict_subset_workspace_bytes(T, nb, bs))
-    ws = t.empty(max(wsb, 8), dtype=t.uint8, device=dev)
+    ws = _workspace(dev, wsb)
     with t.cuda.device(dev):
         check(lib.sd_bd_strict_subset_counts(Xd.data_ptr(), T, n, md.data_ptr(), nb, bs, td.data_ptr(), out.data_ptr(),
                                          ws.data_ptr(), wsb, _stream_ptr(dev)))
@@ -262,15 +304,43 @@ def above_below(X, targets=None, device=None):
     td, m, tp = _targets_dev(targets, M.n, dev)
     out = t.empty((m, M.T, 2), dtype=t.int32, device=dev)
     wsb = M.T * M.n * 8 + 1024
-    ws = t.empty(wsb, dtype=t.uint8, device=dev)
+    ws = _workspace(dev, wsb)
     with t.cuda.device(dev):
         check(lib.sd_above_below(M.tensor.data_ptr(), M.T, M.n, M.st, M.sn, tp, m, out.data_ptr(),
                              ws.data_ptr(), wsb, _stream_ptr(dev)))
     return out.cpu().numpy().astype(np.int64) & 0xFFFFFFFF
 
 
-def bd_strict_counts(X, targets=None, J=2, device=None):
-    """int64[m, J-1]: j-subsets whose band contains the target at every t (sd_bd_strict_j_counts)."""
+def _strict_workspace(lib, dev, M, m, J, budget=None):
+    """(buffer, bytes) for sd_bd_strict_j_counts.  The recommended size holds the masks of a large batch of targets (GiBs
+    at large n); the launcher sizes its batches to whatever it is given, so when the device is short of memory -- the
+    caller keeps other tensors there -- the request shrinks towards the floor of one target per batch instead of failing."""
+    t = torch()
+    want = int(lib.sd_bd_strict_j_workspace_bytes(M.T, M.n, M.st, M.sn, m, J))
+    floor = int(lib.sd_bd_strict_min_workspace_bytes(M.T, M.n, M.st, M.sn, m, J))
+    if budget is not None:
+        want = max(floor, min(want, int(budget)))
+    else:
+        with t.cuda.device(dev):
+            free, _ = t.cuda.mem_get_info()
+        cached = _ws_cache.get(_ws_key(dev))
+        have = free + t.cuda.memory_reserved(dev) - t.cuda.memory_allocated(dev) + (cached.numel() if cached is not None else 0)
+        want = max(floor, min(want, int(have * 0.8)))
+    while True:
+        try:
+            return _workspace(dev, want), want
+        except t.cuda.OutOfMemoryError:
+            if want <= floor:
+                raise
+            release_workspace()
+            t.cuda.empty_cache()
+            want = max(floor, want // 2)
+
+
+def bd_strict_counts(X, targets=None, J=2, device=None, workspace_budget=None):
+    """int64[m, J-1]: j-subsets whose band contains the target at every t (sd_bd_strict_j_counts).
+    workspace_budget: upper bound in bytes for the scratch buffer (default: the recommended size, or what the device has
+    free); never below the floor of one target per batch."""
     t = torch()
     lib = _native.require_device()
     M = to_device_matrix(X, device)
@@ -279,8 +349,7 @@ def bd_strict_counts(X, targets=None, J=2, device=None):
     out = t.empty((m, J - 1), dtype=t.int64, device=dev)
     if m == 0:
         return out.cpu().numpy()
-    wsb = lib.sd_bd_strict_j_workspace_bytes(M.T, M.n, M.st, M.sn, m, J)
-    ws = t.empty(max(int(wsb), 8), dtype=t.uint8, device=dev)
+    ws, wsb = _strict_workspace(lib, dev, M, m, J, workspace_budget)
     with t.cuda.device(dev):
         check(lib.sd_bd_strict_j_counts(M.tensor.data_ptr(), M.T, M.n, M.st, M.sn, tp, m, J,
                                     out.data_ptr(), ws.data_ptr(), wsb, _stream_ptr(dev)))
@@ -354,11 +423,12 @@ def multi_simplex_counts(P, targets=None, relax=True, tol=1e-7, samples=None, se
     return out.cpu().numpy()
 
 
-def _members_dev(members, dev):
+def _members_dev(members, dev, n):
     t = torch()
     mem = np.ascontiguousarray(np.asarray(members, dtype=np.int32))
     if mem.ndim != 2:
         raise ValueError("members must be 2-D (blocks x block size, -1 padded, target last)")
+    _check_members(mem, None, n)
     return t.from_numpy(mem).to(dev), mem.shape[0], mem.shape[1]
 
 
@@ -388,7 +458,7 @@ def pointcloud_simplex_subset_counts(P, members, tol=1e-7, device=None):
     lib = _native.require_device()
     Pd, dev = _points_dev(P, 2, device)
     n, d = Pd.shape
-    md, nb, bs = _members_dev(members, dev)
+    md, nb, bs = _members_dev(members, dev, n)
     out = t.empty(nb, dtype=t.int64, device=dev)
     if nb == 0:
         return out.cpu().numpy()
@@ -422,7 +492,7 @@ def l1_subset_depth(P, members, device=None):
     lib = _native.require_device()
     Pd, dev = _points_dev(P, 2, device)
     n, d = Pd.shape
-    md, nb, bs = _members_dev(members, dev)
+    md, nb, bs = _members_dev(members, dev, n)
     out = t.empty(nb, dtype=t.float64, device=dev)
     if nb == 0:
         return out.cpu().numpy()
@@ -445,7 +515,7 @@ def multi_band_counts(P, targets=None, device=None):
     if m == 0:
         return out.cpu().numpy()
     wsb = int(lib.sd_multi_band_workspace_bytes(n, T, d))
-    ws = t.empty(max(wsb, 8), dtype=t.uint8, device=dev)
+    ws = _workspace(dev, wsb)
     with t.cuda.device(dev):
         check(lib.sd_multi_band_counts(Pd.data_ptr(), n, T, d, tp, m, out.data_ptr(), ws.data_ptr(), wsb, _stream_ptr(dev)))
     return out.cpu().numpy()

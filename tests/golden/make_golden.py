@@ -44,6 +44,21 @@ def _ref():
                 gp=generate_noisy_pointcloud)
 
 
+def _pandas2_append_shim():
+    """pandas >= 2 removed DataFrame.append, which two callers of the hot path still use (_pointcloud.py:118,
+    homogeneity.py:173).  Inside THIS generator process only, give the frame class the pandas-1 method back (a row
+    Series becomes a one-row frame labelled by its name, then pd.concat) so that the reference itself can produce the
+    expected values for those callers.  Nothing of this reaches the product or the tests."""
+    if hasattr(pd.DataFrame, "append"):
+        return
+
+    def append(self, other, ignore_index=False, verify_integrity=False, sort=False):
+        if isinstance(other, pd.Series):
+            other = other.to_frame().T
+        return pd.concat([self, other], ignore_index=ignore_index, verify_integrity=verify_integrity, sort=sort)
+    pd.DataFrame.append = append
+
+
 def _enc(v):
     """JSON-safe float: finite floats as numbers, specials as strings."""
     v = float(v)
@@ -469,6 +484,58 @@ def build_cases():
         return {"name": name, "kind": "duplabels", "ref": "_helper.py:32, _functional.py:232-248",
                 "input": _frame_json(df), "calls": calls, "elapsed_s": time.time() - t0}
     add(duplabel_case, "g11_duplabels")
+
+    # P2: the K-sampled point-cloud depth (_samplepointwisedepth, _pointcloud.py:68-123) -- runs here only with the
+    # DataFrame.append shim; the draws come from the global numpy RNG (data.sample), seeded per case
+    def pc_sampled_case(name, containment, to_compute, K, seed):
+        R = _ref()
+        _pandas2_append_shim()
+        rng = np.random.default_rng(23)
+        n, d = 26, 2
+        df = pd.DataFrame(rng.normal(size=(n, d)), index=[f"p{i}" for i in range(n)], columns=["x", "y"])
+        np.random.seed(seed)
+        t0 = time.time()
+        s = R["PointcloudDepth"](df, to_compute=to_compute, K=K, containment=containment)
+        out = {"name": name, "kind": "pointcloud_sampled", "ref": "_pointcloud.py:68-123",
+               "call": {"containment": containment, "to_compute": to_compute, "K": K, "np_random_seed": seed},
+               "input": _frame_json(df), "elapsed_s": time.time() - t0}
+        out.update(_series_json(s))
+        return out
+    add(lambda name: pc_sampled_case(name, "simplex", ["p3", "p0", "p25", "p11"], 3, 99), "p2_ksampled_simplex")
+    add(lambda name: pc_sampled_case(name, "l1", ["p3", "p0", "p25", "p11"], 3, 99), "p2_ksampled_l1")
+    add(lambda name: pc_sampled_case(name, "simplex", None, 2, 5), "p2_ksampled_simplex_all")
+    add(lambda name: pc_sampled_case(name, "l1", None, 4, 6), "p2_ksampled_l1_all")
+
+    # point-cloud homogeneity (_pointcloudhomogeneity, homogeneity.py:155-200; F.append at :173): same shim.  The
+    # reference demands len(F) == len(G) (:204-205).  'distinct': F and G carry labels of their own; 'shared': the
+    # default RangeIndex on both, where the reference's P3 loop overwrites and drops F's own rows (:183-186) -- kept
+    # as the reference's value for the record.  P4 raises TypeError in the reference (tuple - tuple, :194-195).
+    def pc_homog_case(name, labels, method, containment):
+        if REF not in sys.path:
+            sys.path.insert(0, REF)
+        _pandas2_append_shim()
+        from statdepth.homogeneity import PointcloudHomogeneity
+        rng = np.random.default_rng(31)
+        F = pd.DataFrame(rng.normal(size=(13, 2)))
+        G = pd.DataFrame(rng.normal(size=(13, 2)) * 0.8 + 0.2)
+        if labels == "distinct":
+            F.index = [f"f{i}" for i in range(13)]
+            G.index = [f"g{i}" for i in range(13)]
+        t0 = time.time()
+        out = {"name": name, "kind": "pointcloud_homogeneity", "ref": "homogeneity.py:155-200",
+               "call": {"method": method, "containment": containment, "labels": labels},
+               "input": {"F": _frame_json(F), "G": _frame_json(G)}}
+        try:
+            h = PointcloudHomogeneity(F.copy(), G.copy(), method=method, containment=containment)
+            out["value"] = [_enc(v) for v in np.asarray(h.homogeneity(), dtype=float).ravel()]
+        except Exception as e:                  # noqa: BLE001 -- the exception type is the recorded behaviour
+            out["raises"] = type(e).__name__
+        out["elapsed_s"] = time.time() - t0
+        return out
+    for lab in ("distinct", "shared"):
+        for m in ("p1", "p2", "p3", "p4"):
+            for c in ("simplex", "l1"):
+                add(lambda name, lab=lab, m=m, c=c: pc_homog_case(name, lab, m, c), f"hpc_{lab}_{m}_{c}")
 
     return cases
 

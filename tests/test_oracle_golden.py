@@ -124,6 +124,82 @@ def test_pointcloud(oracle, name):
         assert_depths_close(got, depths_of(fx), TOL)
 
 
+def _sampled_pointcloud_restatement(oracle, df, labels, K, containment):
+    """_samplepointwisedepth (_pointcloud.py:105-121) with the oracle as the exact depth inside each sample: per point
+    ss = n // K draws of data.sample(n=ss) from the global numpy RNG, the point appended when the draw missed it."""
+    import pandas as pd
+    n = len(df)
+    ss = n // K
+    out = []
+    for lab in labels:
+        vals = []
+        for _ in range(ss):
+            sdata = df.sample(n=ss, axis=0)
+            if lab not in sdata.index:
+                sdata = pd.concat([sdata, df.loc[[lab], :]])
+            pos = list(sdata.index).index(lab)
+            fn = oracle.pointcloud_depths if containment == "simplex" else oracle.l1_depth
+            vals.append(fn(sdata.to_numpy(), [pos])[0])
+        out.append(np.mean(vals))
+    return np.array(out)
+
+
+@pytest.mark.parametrize("name", golden_names(kind="pointcloud_sampled"))
+def test_sampled_pointcloud_depth_vs_reference(oracle, name):
+    """P2 pinned to the reference itself (fixtures written by running _samplepointwisedepth under a DataFrame.append shim
+    in the generator): the oracle-based restatement of the draw loop reproduces the reference's values."""
+    from conftest import frame_df
+    fx = load_golden(name)
+    df = frame_df(fx["input"])
+    labels = fx["call"]["to_compute"] or list(df.index)
+    np.random.seed(fx["call"]["np_random_seed"])
+    got = _sampled_pointcloud_restatement(oracle, df, labels, fx["call"]["K"], fx["call"]["containment"])
+    assert fx["index"] == labels
+    assert_depths_close(got, depths_of(fx), TOL)
+
+
+def pointcloud_homogeneity_restatement(oracle, Fx, Gx, method, containment):
+    """_pointcloudhomogeneity (homogeneity.py:155-200) on label-disjoint samples, from oracle depths: `median()` of a
+    depth result is its deepest value; every g is evaluated inside F u {g} (n_F + 1 points)."""
+    def depths(P):
+        return oracle.pointcloud_depths(P) if containment == "simplex" else oracle.l1_depth(P)
+
+    def inside(host, pt):
+        Hp = np.concatenate([host, pt[None, :]])
+        return (oracle.pointcloud_depths(Hp, [len(host)]) if containment == "simplex" else oracle.l1_depth(Hp, [len(host)]))[0]
+
+    dF, dG = depths(Fx), depths(Gx)
+    g_in_F = inside(Fx, Gx[np.argmax(dG)])
+    if method == "p1":
+        return g_in_F / dF.max()
+    if method == "p2":
+        return 1 - abs(g_in_F - dF.max())
+    p3 = max(inside(Fx, g) for g in Gx) / dG.max()
+    if method == "p3":
+        return p3
+    return abs(p3 - inside(Fx, Fx[np.argmax(dF)]) / dF.max()) * abs(p3 - inside(Gx, Gx[np.argmax(dG)]) / dG.max())
+
+
+@pytest.mark.parametrize("name", golden_names(kind="pointcloud_homogeneity"))
+def test_pointcloud_homogeneity_vs_reference(oracle, name):
+    """Point-cloud homogeneity pinned to the reference itself (same shim).  Label-disjoint samples: P1-P3 equal the
+    restatement.  Shared labels (default RangeIndex): P1 / P2 still do; P3 is where the reference overwrites and drops
+    F's own rows (homogeneity.py:183-186) -- its value is on record and is NOT the definition's.  P4 raises TypeError in
+    the reference (tuple - tuple, :194-195)."""
+    fx = load_golden(name)
+    c = fx["call"]
+    if c["method"] == "p4":
+        assert fx.get("raises") == "TypeError"
+        return
+    Fx, Gx = frame_values(fx["input"]["F"]), frame_values(fx["input"]["G"])
+    want = float(fx["value"][0])
+    got = pointcloud_homogeneity_restatement(oracle, Fx, Gx, c["method"], c["containment"])
+    if c["labels"] == "shared" and c["method"] == "p3":
+        assert abs(got - want) > 1e-6
+    else:
+        assert abs(got - want) <= TOL * max(1.0, abs(want))
+
+
 def test_hull_restatement_vs_lp_call(oracle):
     """Geometric restatement == the reference's third-party LP call on random and degenerate sets."""
     from oracle import oracle_np
