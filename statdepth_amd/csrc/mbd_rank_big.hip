@@ -59,15 +59,20 @@ constexpr int BIG_NT = 1024, BIG_E = 16;
 constexpr int BIG_C = BIG_NT * BIG_E;          // 16384 keys per chunk
 using BigCfg = R2Cfg<BIG_NT, BIG_E>;
 
-// grid = (nchunks, rows_in_batch); rowflag != nullptr: only rows with a non-zero flag
-__global__ __launch_bounds__(BIG_NT) void chunk_sort_kernel(const double *__restrict__ Y, i64 n, i64 row0,
+// persistent 1-D grid over (chunk, row); rowflag != nullptr: only rows with a non-zero flag (none: every workgroup reads
+// a few flags and leaves)
+__global__ __launch_bounds__(BIG_NT) void chunk_sort_kernel(const double *__restrict__ Y, i64 n, i64 row0, i64 rows, i64 nch,
                                                             double *__restrict__ sorted, i64 sstride,
                                                             u32 *__restrict__ nanrow, const u32 *__restrict__ rowflag) {
     constexpr int E = BIG_E, WB = BigCfg::WB;
     extern __shared__ double Sm[];
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const i64 c = blockIdx.x, rb = blockIdx.y;
-    if (rowflag && !rowflag[rb]) return;
+    for (i64 v = blockIdx.x; v < rows * nch; v += gridDim.x) {
+    const i64 c = v % nch, rb = v / nch;
+    if (rowflag && !rowflag[rb]) continue;
+    int t = threadIdx.x;
+    asm volatile("" : "+v"(t));                               // per-item opaque thread id: no address hoisted out of the loop
+    const int lane = t & 63, wave = t >> 6;
+    __syncthreads();                                          // the previous item's sort image is no longer in use
     const i64 base = c * BIG_C;
     const int nc = (int)((n - base) < BIG_C ? (n - base) : BIG_C);
     const int n_act = ((nc + WB - 1) / WB) * WB;
@@ -94,6 +99,7 @@ __global__ __launch_bounds__(BIG_NT) void chunk_sort_kernel(const double *__rest
         double *dst = sorted + rb * sstride + base + (i64)t * E;
 #pragma unroll
         for (int r = 0; r < E; ++r) dst[r] = k[r];
+    }
     }
 }
 
@@ -183,6 +189,7 @@ static inline int bucket_count(i64 n) {
 // S: grid = rows; spl[r][0..NB-2] ascending.  SNT threads sort a strided sample of SE SNT values: 2 048 for up to 24
 // value buckets, 4 096 up to 72, 16 384 above (a bucket's fill scatters with 1 / sqrt(samples per bucket); at n = 10^6 the small
 // sample overflowed the 8 192-key buckets and sent every row to the chunked route).
+#ifdef SD_CROSSCHECK
 template <int SNT, int SE>
 __global__ __launch_bounds__(SNT) void bucket_splitters_kernel(const double *__restrict__ Y, i64 n, i64 row0, int NB,
                                                                double *__restrict__ spl) {
@@ -212,7 +219,6 @@ __global__ __launch_bounds__(SNT) void bucket_splitters_kernel(const double *__r
 }
 
 // P: grid = (ceil(n / 16384), rows)
-#ifdef SD_CROSSCHECK
 __global__ __launch_bounds__(1024) void bucket_partition_kernel(const double *__restrict__ Y, i64 n, i64 row0, int NB,
                                                                 const double *__restrict__ spl,
                                                                 u32 *__restrict__ bcnt, u32 *__restrict__ nnanrow,
@@ -281,9 +287,8 @@ __global__ __launch_bounds__(1024) void bucket_partition_kernel(const double *__
     }
     if (over) ovf[rb] = 1u;
 }
-#endif  // SD_CROSSCHECK
 
-// P' (default): the same partition with the scatter staged through LDS.  One workgroup takes 8 192 consecutive curves
+// P' (second generation): the same partition with the scatter staged through LDS.  One workgroup takes 8 192 consecutive curves
 // of one row, orders them by value bucket inside LDS (local slot = LDS-atomic offset + local exclusive prefix of the
 // workgroup's bucket counts) and copies the ordered block out: consecutive threads write consecutive elements of a
 // bucket's run, so the 12-byte records leave as coalesced stores instead of ~19 interleaved partial runs per wave
@@ -383,6 +388,7 @@ __global__ __launch_bounds__(BP2_NT) void bucket_partition2_kernel(const double 
     }
     if (over) ovf[rb] = 1u;
 }
+#endif  // SD_CROSSCHECK
 
 template <int NT, int E>
 struct BkKeys {
@@ -504,12 +510,10 @@ static_assert(BR_NBF / 2 / BR_NT == 4, "one 16-byte quad of histogram words per 
 constexpr size_t BR_HDR = 256;                                         // min/max partials [NW][2] doubles, wave totals [NW]
 constexpr size_t BR_LDS = BR_HDR + (size_t)(BR_NBF / 2 + 4) * 4 + (size_t)(BK_C + BR_PAD + 2 * BR_U2 + 4) * 8;
 
-__global__ __launch_bounds__(BR_NT) void bucket_rank_kernel(i64 n, i64 rows, int NB, const u32 *__restrict__ bcnt,
-                                                            const u32 *__restrict__ nnanrow,
-                                                            const u32 *__restrict__ ovf,
-                                                            const double *__restrict__ bval,
-                                                            const u32 *__restrict__ bidx, u32 *__restrict__ bflag,
-                                                            AB2 ab) {
+__device__ __forceinline__ void bucket_rank_item(const int w, i64 n, i64 rows, int NB, const u32 *__restrict__ bcnt,
+                                                 const u32 *__restrict__ nnanrow, const u32 *__restrict__ ovf,
+                                                 const u32 *__restrict__ rowtied, const double *__restrict__ bval,
+                                                 const u32 *__restrict__ bidx, u32 *__restrict__ bflag, AB2 ab) {
     constexpr int E = BR_E, NT = BR_NT, NBF = BR_NBF, NW = BR_NW, U2 = BR_U2;
     extern __shared__ double Sm[];
     double *red = Sm;                                                 // [NW][2]
@@ -522,11 +526,11 @@ __global__ __launch_bounds__(BR_NT) void bucket_rank_kernel(i64 n, i64 rows, int
     // XCD-aware mapping (workgroups go to the 8 XCDs round-robin): all value buckets of a row run on ONE XCD, close in
     // time, so the 8-byte pair writes they scatter over that row of the image meet in that XCD's L2 and leave it as
     // whole lines.  grid.x = 8 * NB * ceil(rows / 8).
-    const int w = blockIdx.x;
     const int b = (w >> 3) % NB;
     const i64 rb = (i64)((w >> 3) / NB) * 8 + (w & 7);
     if (rb >= rows) return;
     if (ovf[rb]) return;
+    if (rowtied && !rowtied[rb]) return;                              // third generation: only the rows flagged "tied"
     const u32 *rowcnt = bcnt + rb * NB;
     const int cnt = (int)rowcnt[b];
     if (cnt == 0) return;
@@ -703,57 +707,578 @@ __global__ __launch_bounds__(BR_NT) void bucket_rank_kernel(i64 n, i64 rows, int
     }
 }
 
-// B: grid = (NB, rows), flagged buckets only
-__global__ __launch_bounds__(BK_NT) void bucket_search_kernel(i64 n, int NB, const u32 *__restrict__ bcnt,
+
+#ifdef SD_CROSSCHECK
+// A' as a kernel of its own (second generation, cross-check builds): grid = 8 * NB * ceil(rows / 8), every row
+__global__ __launch_bounds__(BR_NT) void bucket_rank_kernel(i64 n, i64 rows, int NB, const u32 *__restrict__ bcnt,
+                                                            const u32 *__restrict__ nnanrow,
+                                                            const u32 *__restrict__ ovf,
+                                                            const double *__restrict__ bval,
+                                                            const u32 *__restrict__ bidx, u32 *__restrict__ bflag,
+                                                            AB2 ab) {
+    bucket_rank_item(blockIdx.x, n, rows, NB, bcnt, nnanrow, ovf, nullptr, bval, bidx, bflag, ab);
+}
+#endif
+
+// =====================================================================================================
+// route 1, third generation (round 3): 8-byte records, table-driven partition, 32-bit ranking
+// =====================================================================================================
+// What changed against S / P' / A' above, and why (profiles/r02b_config3_*): P' spent 91 VALU + 46 SALU per key on a
+// binary search over the splitters and wrote 12-byte records; A' compared fp64 keys (half rate on MI355X) out of 8-byte
+// LDS slots with 63 % of its LDS cycles lost to bank conflicts; three fallback launches of full grids did nothing.
+//   S3 bucket_setup_kernel      the sample sort of S, then per row: NB + 1 splitters (the sample's extremes are splitters
+//                               too: the keys beyond them form two small end buckets), a LOOK-UP TABLE over TB_C cells of
+//                               the monotone map c(x) = trunc((x - lo) * scale) holding, per cell, the number of splitters
+//                               in earlier cells and up to this cell; a "tied" flag when the sorted sample has two equal
+//                               neighbours; and the zeroing of the row's counters (no memset launch).
+//   P3 bucket_partition3_kernel bucket(x) = number of splitters < x as before, but from the table: a compare is needed
+//                               only in cells that a splitter cuts.  Records are 8 bytes: the curve index and a 32-bit
+//                               IMAGE q of the key, monotone inside its bucket (interior buckets: linear between the two
+//                               splitters; end buckets: a float-like code of the distance to the splitter in representable
+//                               doubles) -- equal keys have equal images, different keys almost always different ones.
+//                               Rows flagged "tied" keep the 12-byte fp64 records (their images would collide en masse).
+//   A3 bucket_rank32_kernel     the bucket ranking of A' on the 32-bit images: 4-byte LDS slots, integer compares, no
+//                               range reduction in fp64.  A key whose image equals another member's settles the order of
+//                               those members with their fp64 values (gathered from the matrix through the records' curve
+//                               indices): exact whatever the data, cheap because it is rare on continuous data.
+//                               Tied rows go through bucket_rank_kernel (fp64) as before.
+constexpr int TB_C = 2048;                                             // cells of the partition's look-up table
+constexpr u32 Q_MAX = 0xFFFFFFFEu;                                     // largest image (0xFFFFFFFF = "no key" in LDS)
+
+__device__ __forceinline__ u32 tb_cell(double x, double lo, double scale) {
+    double u = (x - lo) * scale;                                       // monotone in x for any lo and any scale >= 0
+    u = u > 0.0 ? u : 0.0;                                             // NaN (inf * 0) -> 0
+    u = u < (double)(TB_C - 1) ? u : (double)(TB_C - 1);
+    return (u32)u;
+}
+// order-preserving 64-bit pattern of a double (zeros canonicalised by the caller: x + 0.0)
+__device__ __forceinline__ u64 q_ord(double x) {
+    const u64 b = (u64)__double_as_longlong(x);
+    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+// monotone 32-bit code of a 64-bit distance: exact below 2^27, then 26 mantissa bits under a 6-bit length field
+__device__ __forceinline__ u32 q_code(u64 d) {
+    if (d < (1ull << 27)) return (u32)d;
+    const int e = 64 - __builtin_clzll(d);                              // 28 .. 64
+    const u32 mant = (u32)(d >> (e - 27));                              // [2^26, 2^27)
+    return ((u32)(e - 26) << 26) + (mant - (1u << 26));
+}
+
+template <bool MAX>
+__device__ __forceinline__ u32 rb_mmu(u32 a, u32 b) { return MAX ? (a > b ? a : b) : (a < b ? a : b); }
+template <bool MAX>
+__device__ __forceinline__ u32 rb_wave_allreduce_u32(u32 v) {
+    v = rb_mmu<MAX>(v, (u32)__builtin_amdgcn_mov_dpp((int)v, 0x121, 0xF, 0xF, false));
+    v = rb_mmu<MAX>(v, (u32)__builtin_amdgcn_mov_dpp((int)v, 0x122, 0xF, 0xF, false));
+    v = rb_mmu<MAX>(v, (u32)__builtin_amdgcn_mov_dpp((int)v, 0x124, 0xF, 0xF, false));
+    v = rb_mmu<MAX>(v, (u32)__builtin_amdgcn_mov_dpp((int)v, 0x128, 0xF, 0xF, false));
+    u32 r = rb_readlane(v, 0);
+    r = rb_mmu<MAX>(r, rb_readlane(v, 16));
+    r = rb_mmu<MAX>(r, rb_readlane(v, 32));
+    r = rb_mmu<MAX>(r, rb_readlane(v, 48));
+    return r;
+}
+
+// S3: grid = rows.  NB = interior buckets; NBT = NB + 2 buckets and NS = NB + 1 splitters per row.
+template <int SNT, int SE>
+__global__ __launch_bounds__(SNT) void bucket_setup_kernel(const double *__restrict__ Y, i64 n, i64 row0, int NB,
+                                                           double *__restrict__ spl, double *__restrict__ mk,
+                                                           u32 *__restrict__ tab, double2 *__restrict__ rp,
+                                                           u32 *__restrict__ rowtied, u32 *__restrict__ bcnt,
+                                                           u32 *__restrict__ bflag, u32 *__restrict__ nnanrow,
+                                                           u32 *__restrict__ ovf, u32 *__restrict__ nanf) {
+    using Cfg = R2Cfg<SNT, SE>;
+    constexpr int E = SE, LE = Cfg::LE, SS = SNT * SE, NWV = SNT / 64, CPT = TB_C / SNT;
+    static_assert(TB_C % SNT == 0, "whole cells per thread");
+    extern __shared__ double Sm[];
+    __shared__ u32 s_cnt[TB_C];
+    __shared__ u32 s_w[16];
+    __shared__ u32 s_inf[2];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const i64 rb = blockIdx.x;
+    const int NBT = NB + 2, NS = NB + 1;
+    const double *row = Y + (row0 + rb) * n;
+    const double INF = __builtin_huge_val();
+    double k[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const i64 sidx = (i64)t * E + e;
+        double v = row[(sidx * n) / SS];
+        k[e] = (v == v) ? v : INF;
+    }
+    for (int c = t; c < TB_C; c += SNT) s_cnt[c] = 0;
+    if (t < 2) s_inf[t] = 0;
+    // the row's counters (the partition adds to them): zeroed here, no memset launch
+    for (int b = t; b < NBT; b += SNT) {
+        bcnt[rb * NBT + b] = 0;
+        bflag[rb * NBT + b] = 0;
+    }
+    if (t == 0) { nnanrow[rb] = 0; ovf[rb] = 0; nanf[rb] = 0; }
+    R2Sorter<SNT, SE>::sort(k, Sm, t, SS, true, INF);
+    double *Sw = Sm + r2_base<0, LE>(t);
+#pragma unroll
+    for (int e = 0; e < E; ++e) Sw[r2_off<0, LE>(e)] = k[e];
+    u32 cpos = 0, cneg = 0;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        cpos += (k[e] == INF) ? 1u : 0u;
+        cneg += (k[e] == -INF) ? 1u : 0u;
+    }
+    if (cpos) atomicAdd(&s_inf[0], cpos);
+    if (cneg) atomicAdd(&s_inf[1], cneg);
+    __syncthreads();
+    // two equal neighbours in the sorted sample: the row is tie-heavy (or holds several NaN / infinities)
+    bool tie = false;
+#pragma unroll
+    for (int e = 0; e + 1 < E; ++e) tie |= k[e] == k[e + 1];
+    if (t + 1 < SNT) tie |= k[E - 1] == Sm[r2_phys<LE>((t + 1) * E)];
+    const int anytie = __syncthreads_or(tie);
+    // cell map over the finite part of the sample
+    const int ilo = (int)(s_inf[1] < (u32)(SS - 1) ? s_inf[1] : (u32)(SS - 1));
+    const int ihi = SS - 1 - (int)(s_inf[0] < (u32)(SS - 1) ? s_inf[0] : (u32)(SS - 1));
+    const double lo = Sm[r2_phys<LE>(ilo)], hi = Sm[r2_phys<LE>(ihi)];
+    double scale = (double)TB_C / (hi - lo);
+    if (!(scale > 0.0 && scale < INF)) scale = 0.0;                     // degenerate range: one cell, plain search
+    for (int j = t; j < NS; j += SNT) {
+        const int pos = (j == 0) ? 0 : (j == NS - 1) ? SS - 1 : (int)(((i64)j * SS) / NB);
+        const double sj = Sm[r2_phys<LE>(pos)] + 0.0;                   // -0 -> +0
+        spl[rb * NS + j] = sj;
+        atomicAdd(&s_cnt[tb_cell(sj, lo, scale)], 1u);
+        if (j >= 1) {                                                   // interior bucket j = (s_{j-1}, s_j]
+            const int pp = (j - 1 == 0) ? 0 : (int)(((i64)(j - 1) * SS) / NB);
+            const double sp = Sm[r2_phys<LE>(pp)] + 0.0;
+            mk[rb * NBT + j] = (double)Q_MAX / (sj - sp);
+        }
+    }
+    if (t == 0) {
+        mk[rb * NBT] = 0.0;
+        mk[rb * NBT + NBT - 1] = 0.0;
+        rp[rb] = make_double2(lo, scale);
+        rowtied[rb] = anytie ? 1u : 0u;
+    }
+    __syncthreads();
+    // per cell: splitters in earlier cells | splitters up to and including this cell
+    u32 c[CPT], run = 0;
+#pragma unroll
+    for (int q = 0; q < CPT; ++q) { c[q] = s_cnt[t * CPT + q]; run += c[q]; }
+    const u32 incl = rb_wave_incl_scan(run);
+    if (lane == 63) s_w[wave] = incl;
+    __syncthreads();
+    u32 base = incl - run;
+    for (int w = 0; w < wave; ++w) base += s_w[w];
+    (void)NWV;
+#pragma unroll
+    for (int q = 0; q < CPT; ++q) {
+        tab[rb * TB_C + t * CPT + q] = base | ((base + c[q]) << 16);
+        base += c[q];
+    }
+}
+
+// P3: grid = (ceil(n / 4096), rows), 512 threads x 8 keys
+constexpr int P3_NT = 512, P3_E = 8, P3_C = P3_NT * P3_E;
+static inline size_t p3_lds_bytes(int NBT) {
+    return (size_t)P3_C * 8 + (size_t)(2 * NBT + 2) * 8 + (size_t)TB_C * 4 + (size_t)(3 * NBT + 4 + P3_NT / 64) * 4 + (size_t)P3_C * 2 + 64;
+}
+__global__ __launch_bounds__(P3_NT) void bucket_partition3_kernel(const double *__restrict__ Y, i64 n, i64 row0, int NBT,
+                                                                  const double *__restrict__ spl,
+                                                                  const double *__restrict__ mk,
+                                                                  const u32 *__restrict__ tab,
+                                                                  const double2 *__restrict__ rp,
+                                                                  const u32 *__restrict__ rowtied,
+                                                                  u32 *__restrict__ bcnt, u32 *__restrict__ nnanrow,
+                                                                  u32 *__restrict__ ovf, u64 *__restrict__ rec,
+                                                                  u32 *__restrict__ bidx, AB2 ab) {
+    extern __shared__ double Sm3[];
+    const int NS = NBT - 1;
+    u64 *stage = reinterpret_cast<u64 *>(Sm3);                         // [P3_C] records in bucket order
+    double *s_spl = Sm3 + P3_C;                                        // [NS]
+    double *s_mk = s_spl + NBT;                                        // [NBT]
+    u32 *s_tab = reinterpret_cast<u32 *>(s_mk + NBT + 2);              // [TB_C]
+    u32 *s_hist = s_tab + TB_C;                                        // [NBT]
+    u32 *s_gbase = s_hist + NBT;                                       // [NBT]
+    u32 *s_lbase = s_gbase + NBT;                                      // [NBT + 1]
+    u32 *s_wtot = s_lbase + NBT + 2;                                   // [P3_NT / 64]
+    unsigned short *sbk = reinterpret_cast<unsigned short *>(s_wtot + P3_NT / 64 + 1);   // [P3_C]
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const i64 rb = blockIdx.y;
+    const i64 base = (i64)blockIdx.x * P3_C;
+    const double *row = Y + (row0 + rb) * n;
+    double x[P3_E];
+#pragma unroll
+    for (int e = 0; e < P3_E; ++e) {
+        const i64 i = base + t + e * P3_NT;
+        x[e] = (i < n) ? row[i] : 0.0;
+    }
+    for (int c = t; c < TB_C; c += P3_NT) s_tab[c] = tab[rb * TB_C + c];
+    for (int b = t; b < NBT; b += P3_NT) {
+        if (b < NS) s_spl[b] = spl[rb * NS + b];
+        s_mk[b] = mk[rb * NBT + b];
+        s_hist[b] = 0;
+    }
+    const double2 prm = rp[rb];
+    const bool tied = rowtied[rb] != 0;                                // block-uniform
+    __syncthreads();
+    u32 bk[P3_E], off[P3_E], q[P3_E];
+    u32 mynan = 0;
+#pragma unroll
+    for (int e = 0; e < P3_E; ++e) {
+        const i64 i = base + t + e * P3_NT;
+        bk[e] = 0xFFFFFFFFu;
+        off[e] = 0;
+        q[e] = 0;
+        if (i < n) {
+            const double xv = x[e];
+            if (xv == xv) {
+                const u32 tb = s_tab[tb_cell(xv, prm.x, prm.y)];
+                int a = (int)(tb & 0xFFFFu), b = (int)(tb >> 16);       // bucket = number of splitters < x, in [a, b]
+                while (a < b) {
+                    const int mid = (a + b) >> 1;
+                    if (s_spl[mid] < xv) a = mid + 1;
+                    else b = mid;
+                }
+                bk[e] = (u32)a;
+                off[e] = atomicAdd(&s_hist[a], 1u);
+                if (!tied) {
+                    const double xc = xv + 0.0;
+                    u32 qq;
+                    if (a == 0) {
+                        const u32 cd = q_code(q_ord(s_spl[0]) - q_ord(xc));
+                        qq = Q_MAX - (cd < Q_MAX ? cd : Q_MAX);
+                    } else if (a == NS) {
+                        const u32 cd = q_code(q_ord(xc) - q_ord(s_spl[NS - 1]));
+                        qq = cd < Q_MAX ? cd : Q_MAX;
+                    } else {
+                        double v = (xc - s_spl[a - 1]) * s_mk[a];
+                        v = v < (double)Q_MAX ? v : (double)Q_MAX;     // NaN -> Q_MAX
+                        qq = (u32)v;
+                    }
+                    q[e] = qq;
+                }
+            } else {
+                ++mynan;
+                ab.B[rb * n + i] = AB2_NAN;
+            }
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) mynan += __shfl_down(mynan, o);
+    if (lane == 0 && mynan) atomicAdd(&nnanrow[rb], mynan);
+    __syncthreads();
+    // global base of this workgroup's run in every bucket; local exclusive prefix of its counts.  Thread t owns the
+    // buckets [t * per, t * per + per).
+    {
+        const int per = (NBT + P3_NT - 1) / P3_NT;                     // <= 3
+        u32 run = 0;
+        for (int r = 0; r < per; ++r) {
+            const int b = t * per + r;
+            if (b < NBT) {
+                const u32 c = s_hist[b];
+                s_gbase[b] = c ? atomicAdd(&bcnt[rb * NBT + b], c) : 0u;
+                run += c;
+            }
+        }
+        const u32 incl = rb_wave_incl_scan(run);
+        if (lane == 63) s_wtot[wave] = incl;
+        __syncthreads();
+        u32 o = incl - run;
+        for (int w = 0; w < wave; ++w) o += s_wtot[w];
+        for (int r = 0; r < per; ++r) {
+            const int b = t * per + r;
+            if (b < NBT) {
+                s_lbase[b] = o;
+                o += s_hist[b];
+            }
+        }
+        if (t == P3_NT - 1) s_lbase[NBT] = o;                           // non-NaN keys of the block
+    }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < P3_E; ++e) {
+        if (bk[e] != 0xFFFFFFFFu) {
+            const u32 lp = s_lbase[bk[e]] + off[e];
+            const u32 id = (u32)(base + t + e * P3_NT);
+            stage[lp] = tied ? (u64)__double_as_longlong(x[e]) : ((u64)q[e] | ((u64)id << 32));
+            sbk[lp] = (unsigned short)bk[e];
+        }
+    }
+    __syncthreads();
+    const u32 nval = s_lbase[NBT];
+    bool over = false;
+    for (u32 p = t; p < nval; p += P3_NT) {
+        const u32 b = sbk[p];
+        const u32 g = s_gbase[b] + (p - s_lbase[b]);
+        if (g < (u32)BK_C) rec[((size_t)rb * NBT + b) * BK_C + g] = stage[p];
+        else over = true;
+    }
+    if (over) ovf[rb] = 1u;
+    if (tied) {                                                        // fp64 records: the curve indices in a second round
+        __syncthreads();
+        u32 *stage32 = reinterpret_cast<u32 *>(stage);
+#pragma unroll
+        for (int e = 0; e < P3_E; ++e)
+            if (bk[e] != 0xFFFFFFFFu) stage32[s_lbase[bk[e]] + off[e]] = (u32)(base + t + e * P3_NT);
+        __syncthreads();
+        for (u32 p = t; p < nval; p += P3_NT) {
+            const u32 b = sbk[p];
+            const u32 g = s_gbase[b] + (p - s_lbase[b]);
+            if (g < (u32)BK_C) bidx[((size_t)rb * NBT + b) * BK_C + g] = stage32[p];
+        }
+    }
+}
+
+// A3: grid = 8 * NBT * ceil(rows / 8) (the XCD-aware mapping of bucket_rank_kernel), 512 threads x 16 keys
+constexpr int A3_NT = 512, A3_E = 16, A3_LNB = 12, A3_NBF = 1 << A3_LNB, A3_CAP = 63, A3_U = 2, A3_PAD = 32;
+constexpr int A3_NW = A3_NT / 64;
+static_assert(A3_NT * A3_E == BK_C, "one thread slot per key of a full value bucket");
+static_assert(A3_NBF / 2 / A3_NT == 4, "one 16-byte quad of histogram words per thread");
+constexpr size_t A3_HDR = 256;
+constexpr size_t A3_LDS32 = A3_HDR + (size_t)(A3_NBF / 2 + 4) * 4 + (size_t)(BK_C + A3_PAD) * 4 + (size_t)(BK_C + A3_PAD) * 2;
+constexpr size_t A3_LDS = A3_LDS32 > BR_LDS ? A3_LDS32 : BR_LDS;      // rows flagged "tied" run A' inside this kernel
+
+__global__ __launch_bounds__(A3_NT) void bucket_rank32_kernel(const double *__restrict__ Y, i64 n, i64 row0, i64 rows, int NBT,
+                                                              const u32 *__restrict__ bcnt,
+                                                              const u32 *__restrict__ nnanrow,
+                                                              const u32 *__restrict__ ovf,
+                                                              const u32 *__restrict__ rowtied,
+                                                              const u64 *__restrict__ rec,
+                                                              const u32 *__restrict__ bidx, u32 *__restrict__ bflag,
+                                                              AB2 ab) {
+    constexpr int E = A3_E, NT = A3_NT, NBF = A3_NBF, NW = A3_NW, U = A3_U;
+    extern __shared__ double Sm[];
+    u32 *red = reinterpret_cast<u32 *>(Sm);                            // [NW][2] min / max, then [NW] earlier-bucket sums
+    u32 *wtot = red + 2 * NW;                                          // [NW]
+    u32 *H = reinterpret_cast<u32 *>(Sm + A3_HDR / 8);                 // NBF packed u16 counters, then bases
+    u32 *S = H + NBF / 2 + 4;                                          // images in fine-bucket order + sentinels
+    unsigned short *Jx = reinterpret_cast<unsigned short *>(S + BK_C + A3_PAD);   // record slot of every image
+    const unsigned short *H16 = reinterpret_cast<const unsigned short *>(H);
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int w = blockIdx.x;
+    const int b = (w >> 3) % NBT;
+    const i64 rb = (i64)((w >> 3) / NBT) * 8 + (w & 7);
+    if (rb >= rows) return;
+    if (ovf[rb]) return;
+    if (rowtied[rb]) {                                                // block-uniform: fp64 records, A' (same LDS, same grid)
+        bucket_rank_item(w, n, rows, NBT, bcnt, nnanrow, ovf, rowtied, reinterpret_cast<const double *>(rec), bidx, bflag, ab);
+        return;
+    }
+    const u32 *rowcnt = bcnt + rb * NBT;
+    const int cnt = (int)rowcnt[b];
+    if (cnt == 0) return;
+    const size_t slot0 = ((size_t)rb * NBT + b) * BK_C;
+
+    u32 q[E], id[E];
+    {
+        const u64 *rp = rec + slot0 + t;
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const u64 r = (t + e * NT < cnt) ? rp[e * NT] : 0xFFFFFFFFull;
+            q[e] = (u32)r;
+            id[e] = (u32)(r >> 32);
+        }
+    }
+    u32 gsum = 0;
+    for (int k = t; k < b; k += NT) gsum += rowcnt[k];
+    gsum = rb_wave_incl_scan(gsum);
+    reinterpret_cast<uint4 *>(H)[t] = make_uint4(0, 0, 0, 0);
+    if (t < 4) H[NBF / 2 + t] = 0;
+    if (t < A3_PAD) S[cnt + t] = 0xFFFFFFFFu;
+    u32 mn = 0xFFFFFFFFu, mx = 0;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        if (e * NT >= cnt) break;
+        mn = mn < q[e] ? mn : q[e];
+        const u32 v = (t + e * NT < cnt) ? q[e] : 0u;
+        mx = mx > v ? mx : v;
+    }
+    mn = rb_wave_allreduce_u32<false>(mn);
+    mx = rb_wave_allreduce_u32<true>(mx);
+    if (lane == 63) { red[2 * wave] = mn; red[2 * wave + 1] = mx; wtot[wave] = gsum; }
+    __syncthreads();                                                  // barrier 1
+    u32 lo, hi, gbase;
+    {
+        const uint2 pmm = reinterpret_cast<const uint2 *>(red)[lane & (NW - 1)];
+        lo = rb_wave_allreduce_u32<false>(pmm.x);
+        hi = rb_wave_allreduce_u32<true>(pmm.y);
+        const u32 g = (lane < NW) ? wtot[lane] : 0u;
+        gbase = rb_readlane(rb_row_incl_scan(g), 15);
+    }
+    const u32 nreal = (u32)n - nnanrow[rb];
+    const size_t abrow = (size_t)(rb * n);
+    const float fs = (float)NBF / ((float)(hi - lo) + 1.0f);
+    // ---- (1) fine bucket + slot ----
+    u32 bs[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        if (e * NT >= cnt) break;
+        u32 fb = (u32)((float)(q[e] - lo) * fs);                      // monotone in q
+        fb = fb < (u32)(NBF - 1) ? fb : (u32)(NBF - 1);
+        fb = (t + e * NT < cnt) ? fb : (u32)(NBF + 2);                // no key: dummy counter
+        const u32 sh = (fb & 1u) * 16u;
+        const u32 old = atomicAdd(&H[fb >> 1], 1u << sh);
+        bs[e] = fb | (((old >> sh) & 0xFFFFu) << 16);
+    }
+    __syncthreads();                                                  // barrier 2
+    // ---- (2) exclusive prefix sum; a fine bucket above A3_CAP keys: the search kernel takes the value bucket ----
+    bool anyover = false;
+    {
+        const uint4 hq = reinterpret_cast<const uint4 *>(H)[t];
+        constexpr u32 HIM = (0xFFFFu & ~(u32)A3_CAP) * 0x10001u;
+        const u32 s4 = hq.x + hq.y + hq.z + hq.w;
+        const u32 ov = hq.x | hq.y | hq.z | hq.w;
+        const u32 run = (s4 & 0xFFFFu) + (s4 >> 16);
+        const u32 incl = rb_wave_incl_scan(run);
+        const bool wover = __ballot((ov & HIM) != 0) != 0;
+        if (lane == 63) wtot[wave] = incl | (wover ? 0x80000000u : 0u);
+        __syncthreads();                                              // barrier 3
+        const u32 wt = (lane < NW) ? wtot[lane] : 0u;
+        anyover = __ballot((wt >> 31) != 0) != 0;                     // block-uniform
+        const u32 wscan = rb_row_incl_scan(wt & 0x7FFFFFFFu);
+        u32 base = (wave ? rb_readlane(wscan, wave - 1) : 0u) + incl - run;
+        uint4 o;
+        o.x = base | ((base + (hq.x & 0xFFFFu)) << 16);
+        base += (hq.x & 0xFFFFu) + (hq.x >> 16);
+        o.y = base | ((base + (hq.y & 0xFFFFu)) << 16);
+        base += (hq.y & 0xFFFFu) + (hq.y >> 16);
+        o.z = base | ((base + (hq.z & 0xFFFFu)) << 16);
+        base += (hq.z & 0xFFFFu) + (hq.z >> 16);
+        o.w = base | ((base + (hq.w & 0xFFFFu)) << 16);
+        base += (hq.w & 0xFFFFu) + (hq.w >> 16);
+        reinterpret_cast<uint4 *>(H)[t] = o;
+        if (t == NT - 1) H[NBF / 2] = base;                           // = cnt
+    }
+    if (anyover) {                                                    // heavy ties the sample did not show
+        if (t == 0) bflag[rb * NBT + b] = 1u;
+        return;
+    }
+    __syncthreads();                                                  // barrier 4
+    // ---- (3) scatter into fine-bucket order ----
+    u32 bc[E];                                                        // base | count << 16; count 0: no key
+    const u32 dummy = (u32)(cnt + A3_PAD - 1);
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        if (e * NT >= cnt) break;
+        const u32 fb = bs[e] & 0xFFFFu, slot = bs[e] >> 16;
+        const u32 base = H16[fb], end = H16[fb + 1];
+        const bool isk = fb < (u32)NBF;
+        const u32 pos = isk ? base + slot : dummy;
+        S[pos] = isk ? q[e] : 0xFFFFFFFFu;
+        Jx[pos] = (unsigned short)(t + e * NT);
+        bc[e] = isk ? (base | ((end - base) << 16)) : 0u;
+    }
+    __syncthreads();                                                  // barrier 5
+    // ---- (4) rank inside the fine bucket, write B ----
+    const double *yrow = Y + (row0 + rb) * n;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        if (e * NT >= cnt) break;
+        if ((e & 1) == 0) __builtin_amdgcn_sched_barrier(0);
+        const u32 base = bc[e] & 0xFFFFu, fc = bc[e] >> 16;
+        const u32 offq = base & 3u;
+        const u32 x = q[e];
+        const uint4 *Sq = reinterpret_cast<const uint4 *>(S + (base - offq));
+        u32 less = 0, eq = 0;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint4 y = Sq[u];
+            less += (y.x < x) + (y.y < x) + (y.z < x) + (y.w < x);
+            eq += (y.x == x) + (y.y == x) + (y.z == x) + (y.w == x);
+        }
+        if (fc + offq > (u32)(4 * U)) {                               // a fine bucket longer than the window
+            for (u32 kk = 4 * U; kk < fc + offq; kk += 4) {
+                const uint4 y = Sq[kk >> 2];
+                less += (y.x < x) + (y.y < x) + (y.z < x) + (y.w < x);
+                eq += (y.x == x) + (y.y == x) + (y.z == x) + (y.w == x);
+            }
+        }
+        less -= offq;                                                 // keys in front of the base: earlier fine buckets, all smaller
+        if (fc) {
+            if (eq == 1u) {
+                ab.B[abrow + id[e]] = gbase + base + less;            // untied: A = nreal - 1 - B
+            } else {
+                // another member carries the same image: the fp64 values of those members decide
+                const double xv = yrow[id[e]];
+                u32 lt = 0, eqv = 0;
+                for (u32 m = base; m < base + fc; ++m) {
+                    if (S[m] == x) {
+                        const u32 im = (u32)(rec[slot0 + Jx[m]] >> 32);
+                        const double yv = yrow[im];
+                        lt += (yv < xv) ? 1u : 0u;
+                        eqv += (yv == xv) ? 1u : 0u;
+                    }
+                }
+                const u32 Bv = gbase + base + less + lt;
+                ab_store(ab, abrow + id[e], Bv, nreal - (Bv + eqv), nreal);
+            }
+        }
+    }
+}
+
+// B: persistent 1-D grid over the (row, bucket) pairs, flagged buckets only (nothing flagged: every workgroup reads a few
+// flags and leaves).  rowtied == nullptr or rowtied[row]: fp64 records (bval, bidx); else 8-byte records whose keys are
+// gathered from the matrix through their curve indices.
+__global__ __launch_bounds__(BK_NT) void bucket_search_kernel(const double *__restrict__ Y, i64 n, i64 row0, i64 rows, int NB,
+                                                              const u32 *__restrict__ bcnt,
                                                               const u32 *__restrict__ nnanrow,
                                                               const u32 *__restrict__ bflag,
+                                                              const u32 *__restrict__ rowtied,
                                                               const double *__restrict__ bval,
                                                               const u32 *__restrict__ bidx, AB2 ab) {
     using C = BkCfg;
     constexpr int E = BK_E, NT = BK_NT, LE = C::LE, WB = C::WB, N = C::N;
     extern __shared__ double Sm[];
     __shared__ u32 s_basecnt;
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int b = blockIdx.x;
-    const i64 rb = blockIdx.y;
-    if (!bflag[rb * NB + b]) return;
-    const int cnt = (int)bcnt[rb * NB + b];
-    if (t == 0) {
-        u32 s = 0;
-        for (int q = 0; q < b; ++q) s += bcnt[rb * NB + q];
-        s_basecnt = s;
-    }
-    const int n_act = ((cnt + WB - 1) / WB) * WB;
-    const bool wreal = wave * WB < n_act;
-    const double INF = __builtin_huge_val();
-    const size_t slot0 = ((size_t)rb * NB + b) * BK_C;
-    const int i0 = wave * WB + lane;
-    double k[E];
-    if (wreal) {
-        const double *rp = bval + slot0 + i0;
-#pragma unroll
-        for (int e = 0; e < E; ++e) k[e] = (i0 + e * 64 < cnt) ? rp[e * 64] : INF;
-    }
-    R2Sorter<NT, E>::sort(k, Sm, t, n_act, wreal, INF);
-    if (wreal) {
-        double *Sw = Sm + r2_base<0, LE>(t);
-#pragma unroll
-        for (int e = 0; e < E; ++e) Sw[r2_off<0, LE>(e)] = k[e];
-    }
-    __syncthreads();
-    const u32 base = s_basecnt;
-    const u32 nreal = (u32)n - nnanrow[rb];
-    for (int j = t; j < cnt; j += NT) {
-        const double x = bval[slot0 + j];
-        int lo = r2_bound<N, SlotPad<LE>, false, false>(Sm, n_act, x, INF);       // x is in the bucket
-        int hi = lo + 1, step = 1;
-        while (hi + step <= n_act && Sm[r2_phys<LE>(hi + step - 1)] <= x) { hi += step; step <<= 1; }
-        while (step > 1) {
-            step >>= 1;
-            if (hi + step <= n_act && Sm[r2_phys<LE>(hi + step - 1)] <= x) hi += step;
+    const u64 *rec = reinterpret_cast<const u64 *>(bval);
+    for (i64 v = blockIdx.x; v < rows * NB; v += gridDim.x) {
+        if (!bflag[v]) continue;                                      // block-uniform
+        int t = threadIdx.x;
+        asm volatile("" : "+v"(t));                                   // per-item opaque thread id
+        const int lane = t & 63, wave = t >> 6;
+        const int b = (int)(v % NB);
+        const i64 rb = v / NB;
+        const bool packed = rowtied && !rowtied[rb];
+        const double *yrow = Y + (row0 + rb) * n;
+        const int cnt = (int)bcnt[rb * NB + b];
+        __syncthreads();                                              // the previous item's image is no longer read
+        if (t == 0) {
+            u32 sum = 0;
+            for (int q = 0; q < b; ++q) sum += bcnt[rb * NB + q];
+            s_basecnt = sum;
         }
-        // values above x: everything real beyond x's tie run (x = +inf: the padding ties with it, nothing is above)
-        ab_store(ab, (size_t)(rb * n + bidx[slot0 + j]), base + (u32)lo, (x == INF) ? 0u : nreal - (base + (u32)hi), nreal);
+        const int n_act = ((cnt + WB - 1) / WB) * WB;
+        const bool wreal = wave * WB < n_act;
+        const double INF = __builtin_huge_val();
+        const size_t slot0 = ((size_t)rb * NB + b) * BK_C;
+        const int i0 = wave * WB + lane;
+        double k[E];
+        if (wreal) {
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const int j = i0 + e * 64;
+                k[e] = (j < cnt) ? (packed ? yrow[(u32)(rec[slot0 + j] >> 32)] : bval[slot0 + j]) : INF;
+            }
+        }
+        R2Sorter<NT, E>::sort(k, Sm, t, n_act, wreal, INF);
+        if (wreal) {
+            double *Sw = Sm + r2_base<0, LE>(t);
+#pragma unroll
+            for (int e = 0; e < E; ++e) Sw[r2_off<0, LE>(e)] = k[e];
+        }
+        __syncthreads();
+        const u32 base = s_basecnt;
+        const u32 nreal = (u32)n - nnanrow[rb];
+        for (int j = t; j < cnt; j += NT) {
+            const u32 id = packed ? (u32)(rec[slot0 + j] >> 32) : bidx[slot0 + j];
+            const double x = packed ? yrow[id] : bval[slot0 + j];
+            int lo = r2_bound<N, SlotPad<LE>, false, false>(Sm, n_act, x, INF);       // x is in the bucket
+            int hi = lo + 1, step = 1;
+            while (hi + step <= n_act && Sm[r2_phys<LE>(hi + step - 1)] <= x) { hi += step; step <<= 1; }
+            while (step > 1) {
+                step >>= 1;
+                if (hi + step <= n_act && Sm[r2_phys<LE>(hi + step - 1)] <= x) hi += step;
+            }
+            // values above x: everything real beyond x's tie run (x = +inf: the padding ties with it, nothing is above)
+            ab_store(ab, (size_t)(rb * n + id), base + (u32)lo, (x == INF) ? 0u : nreal - (base + (u32)hi), nreal);
+        }
     }
 }
 
@@ -813,10 +1338,10 @@ static inline i64 big_nchunks(i64 n) { return (n + BIG_C - 1) / BIG_C; }
 
 struct BigPlan {
     i64 nch, sstride, rpb;
-    int NB;
-    size_t off_ab, off_sorted, off_bval, off_bidx, off_spl, off_zero, zero_bytes, total;
-    // zeroed block: bcnt[rpb*NB] | nnanrow[rpb] | ovf[rpb] | bflag[rpb*NB] | nanrow_f[rpb]
-    size_t z_bcnt, z_nnan, z_ovf, z_bflag, z_nanf;
+    int NB, NBT;                                         // interior value buckets; NBT = NB + 2 with the two end buckets
+    size_t off_ab, off_sorted, off_bval, off_bidx, off_spl, off_mk, off_tab, off_rp, off_zero, zero_bytes, total;
+    // zeroed block: bcnt[rpb*NBT] | nnanrow[rpb] | ovf[rpb] | bflag[rpb*NBT] | nanrow_f[rpb] | rowtied[rpb]
+    size_t z_bcnt, z_nnan, z_ovf, z_bflag, z_nanf, z_tied;
 };
 
 static BigPlan big_plan(i64 T, i64 n) {
@@ -824,7 +1349,9 @@ static BigPlan big_plan(i64 T, i64 n) {
     p.nch = big_nchunks(n);
     p.sstride = p.nch * BIG_C;
     p.NB = bucket_count(n);
-    const size_t per_row = (size_t)n * 8 + (size_t)p.sstride * 8 + (size_t)p.NB * BK_C * 12 + (size_t)p.NB * 16 + 64;
+    p.NBT = p.NB + 2;
+    const size_t per_row = (size_t)n * 8 + (size_t)p.sstride * 8 + (size_t)p.NBT * BK_C * 12 + (size_t)p.NBT * 32 +
+                           (size_t)TB_C * 4 + 128;
     i64 r = (i64)(((size_t)3 << 29) / per_row);           // ~1.5 GiB of scratch per batch
     const i64 vb = xswitch("SD_RANK_ROWS_PER_BATCH");          // cross-check builds: several batches on small inputs
     if (vb > 0 && vb < r) r = vb;
@@ -836,17 +1363,21 @@ static BigPlan big_plan(i64 T, i64 n) {
     auto take = [&](size_t bytes) { size_t at = o; o = align_up(o + bytes, 256); return at; };
     p.off_ab = take((size_t)r * n * 8);
     p.off_sorted = take((size_t)r * p.sstride * 8);
-    p.off_bval = take((size_t)r * p.NB * BK_C * 8);
-    p.off_bidx = take((size_t)r * p.NB * BK_C * 4);
-    p.off_spl = take((size_t)r * p.NB * 8);
+    p.off_bval = take((size_t)r * p.NBT * BK_C * 8);
+    p.off_bidx = take((size_t)r * p.NBT * BK_C * 4);
+    p.off_spl = take((size_t)r * p.NBT * 8);
+    p.off_mk = take((size_t)r * p.NBT * 8);
+    p.off_tab = take((size_t)r * TB_C * 4);
+    p.off_rp = take((size_t)r * 16);
     p.off_zero = o;
     size_t z = 0;
     auto ztake = [&](size_t bytes) { size_t at = z; z = align_up(z + bytes, 256); return at; };
-    p.z_bcnt = ztake((size_t)r * p.NB * 4);
+    p.z_bcnt = ztake((size_t)r * p.NBT * 4);
     p.z_nnan = ztake((size_t)r * 4);
     p.z_ovf = ztake((size_t)r * 4);
-    p.z_bflag = ztake((size_t)r * p.NB * 4);
+    p.z_bflag = ztake((size_t)r * p.NBT * 4);
     p.z_nanf = ztake((size_t)r * 4);
+    p.z_tied = ztake((size_t)r * 4);
     p.zero_bytes = z;
     p.total = o + z + 256;
     return p;
@@ -855,7 +1386,7 @@ static BigPlan big_plan(i64 T, i64 n) {
 bool mbd_rank_big_supported(i64 T, i64 n, int J) {
     (void)T;
     return n > 16384 && n < ((i64)1 << 31) && J >= 2 && J <= JMAX && big_nchunks(n) <= 1024 &&
-           bucket_count(n) <= BK_MAXNB;
+           bucket_count(n) + 2 <= BK_MAXNB;
 }
 
 size_t mbd_rank_big_workspace_bytes(i64 T, i64 n, int J) {
@@ -876,87 +1407,125 @@ int launch_mbd_rank_big(const double *Y, i64 T, i64 n, const i64 *targets, i64 t
     double *bval = (double *)(w + p.off_bval);
     u32 *bidx = (u32 *)(w + p.off_bidx);
     double *spl = (double *)(w + p.off_spl);
+    double *mk = (double *)(w + p.off_mk);
+    u32 *tab = (u32 *)(w + p.off_tab);
+    double2 *rp = (double2 *)(w + p.off_rp);
     char *zb = w + p.off_zero;
     u32 *bcnt = (u32 *)(zb + p.z_bcnt), *nnanrow = (u32 *)(zb + p.z_nnan), *ovf = (u32 *)(zb + p.z_ovf);
-    u32 *bflag = (u32 *)(zb + p.z_bflag), *nanf = (u32 *)(zb + p.z_nanf);
+    u32 *bflag = (u32 *)(zb + p.z_bflag), *nanf = (u32 *)(zb + p.z_nanf), *rowtied = (u32 *)(zb + p.z_tied);
 
     const bool buckets = xswitch("SD_BIG_IMPL") != 1;       // cross-check builds, 1: chunked route for every row
-    const int NB = p.NB;
+#ifdef SD_CROSSCHECK
+    const bool gen2 = xswitch("SD_BIG_GEN2") == 1 || xswitch("SD_BIG_SORT") == 1 || xswitch("SD_BIG_PART1") == 1;
+#else
+    const bool gen2 = false;
+#endif
+    const int NB = p.NB, NBT = p.NBT;
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) {
         int v = 0;
         if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
     }
+    const unsigned pgrid = (unsigned)(2 * cus);             // small persistent grids (a multiple of 8: XCD mapping)
     auto k_cs = chunk_sort_kernel;
     auto k_cq = chunk_search_kernel;
     // sample per row: 2 048 values up to 24 value buckets (>= 85 samples per bucket), 4 096 up to 72, 16 384 above.
     // The sort of the sample by ONE workgroup is pure latency in front of the partition (4 096 keys: 33 us, as 256 x 16
     // or 1024 x 4 alike), so the sample is no larger than the buckets' capacity margin needs.
+    auto k_s3_small = bucket_setup_kernel<128, 16>;
+    auto k_s3 = bucket_setup_kernel<256, 16>;
+    auto k_s3_big = bucket_setup_kernel<1024, 16>;
+    constexpr size_t lds_sp_small = R2Cfg<128, 16>::LDS_BYTES, lds_sp = R2Cfg<256, 16>::LDS_BYTES;
+    constexpr size_t lds_sp_big = R2Cfg<1024, 16>::LDS_BYTES;
+    auto k_bs = bucket_search_kernel;
+    const size_t lds_p3 = p3_lds_bytes(NBT);
+    SD_HIP(hipFuncSetAttribute((const void *)k_cs, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BigCfg::LDS_BYTES));
+    SD_HIP(hipFuncSetAttribute((const void *)k_cq, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BigCfg::LDS_BYTES));
+    SD_HIP(hipFuncSetAttribute((const void *)k_s3_small, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sp_small));
+    SD_HIP(hipFuncSetAttribute((const void *)k_s3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sp));
+    SD_HIP(hipFuncSetAttribute((const void *)k_s3_big, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sp_big));
+    SD_HIP(hipFuncSetAttribute((const void *)bucket_partition3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_p3));
+    SD_HIP(hipFuncSetAttribute((const void *)bucket_rank32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)A3_LDS));
+    SD_HIP(hipFuncSetAttribute((const void *)k_bs, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BkCfg::LDS_BYTES));
+#ifdef SD_CROSSCHECK
+    auto k_br = bucket_rank_kernel;
+    SD_HIP(hipFuncSetAttribute((const void *)k_br, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BR_LDS));
+    auto k_bp = bucket_packed_kernel;
     auto k_sp_small = bucket_splitters_kernel<128, 16>;
     auto k_sp = bucket_splitters_kernel<256, 16>;
     auto k_sp_big = bucket_splitters_kernel<1024, 16>;
-    constexpr size_t lds_sp_small = R2Cfg<128, 16>::LDS_BYTES, lds_sp = R2Cfg<256, 16>::LDS_BYTES;
-    constexpr size_t lds_sp_big = R2Cfg<1024, 16>::LDS_BYTES;
-    SD_HIP(hipFuncSetAttribute((const void *)k_sp_small, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sp_small));
-    auto k_br = bucket_rank_kernel;
-#ifdef SD_CROSSCHECK
-    auto k_bp = bucket_packed_kernel;
-    const bool rank_nosort = xswitch("SD_BIG_SORT") != 1;   // 1: packed-key sort per value bucket (predecessor)
-#endif
-    auto k_bs = bucket_search_kernel;
-#ifdef SD_CROSSCHECK
     const size_t lds_bk = BkCfg::LDS_BYTES + (size_t)BK_NT * 8;
-#endif
-    SD_HIP(hipFuncSetAttribute((const void *)k_cs, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BigCfg::LDS_BYTES));
-    SD_HIP(hipFuncSetAttribute((const void *)k_cq, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BigCfg::LDS_BYTES));
+    SD_HIP(hipFuncSetAttribute((const void *)k_sp_small, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sp_small));
     SD_HIP(hipFuncSetAttribute((const void *)k_sp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sp));
-    SD_HIP(hipFuncSetAttribute((const void *)k_sp_big, hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)lds_sp_big));
-#ifdef SD_CROSSCHECK
+    SD_HIP(hipFuncSetAttribute((const void *)k_sp_big, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sp_big));
     SD_HIP(hipFuncSetAttribute((const void *)k_bp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bk));
-#endif
-    SD_HIP(hipFuncSetAttribute((const void *)k_br, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BR_LDS));
     SD_HIP(hipFuncSetAttribute((const void *)bucket_partition2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)((size_t)BP2_C * 14)));
-    SD_HIP(hipFuncSetAttribute((const void *)k_bs, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BkCfg::LDS_BYTES));
+#endif
 
     for (i64 row0 = 0; row0 < T; row0 += p.rpb) {
         const i64 rows = T - row0 < p.rpb ? T - row0 : p.rpb;
-        SD_HIP(hipMemsetAsync(zb, 0, p.zero_bytes, s));
         const u32 *fallback_rows = nullptr;                  // chunked route: every row
         const u32 *nn_for_fold = nanf;
-        if (buckets) {
+        if (!buckets || gen2) SD_HIP(hipMemsetAsync(zb, 0, p.zero_bytes, s));      // (the third generation's S3 zeroes)
+        if (buckets && !gen2) {
+            // ---- third generation: S3 -> P3 -> A3 (untied rows) / A' (tied rows) ----
+            if (NB <= 24)
+                hipLaunchKernelGGL(k_s3_small, dim3((unsigned)rows), dim3(128), lds_sp_small, s, Y, n, row0, NB, spl, mk, tab,
+                                   rp, rowtied, bcnt, bflag, nnanrow, ovf, nanf);
+            else if (NB <= 72)
+                hipLaunchKernelGGL(k_s3, dim3((unsigned)rows), dim3(256), lds_sp, s, Y, n, row0, NB, spl, mk, tab, rp,
+                                   rowtied, bcnt, bflag, nnanrow, ovf, nanf);
+            else
+                hipLaunchKernelGGL(k_s3_big, dim3((unsigned)rows), dim3(1024), lds_sp_big, s, Y, n, row0, NB, spl, mk, tab,
+                                   rp, rowtied, bcnt, bflag, nnanrow, ovf, nanf);
+            hipLaunchKernelGGL(bucket_partition3_kernel, dim3((unsigned)((n + P3_C - 1) / P3_C), (unsigned)rows), dim3(P3_NT),
+                               lds_p3, s, Y, n, row0, NBT, (const double *)spl, (const double *)mk, (const u32 *)tab,
+                               (const double2 *)rp, (const u32 *)rowtied, bcnt, nnanrow, ovf, (u64 *)bval, bidx, ab);
+            hipLaunchKernelGGL(bucket_rank32_kernel, dim3((unsigned)(8 * NBT * ((rows + 7) / 8))), dim3(A3_NT), A3_LDS, s, Y, n,
+                               row0, rows, NBT, (const u32 *)bcnt, (const u32 *)nnanrow, (const u32 *)ovf,
+                               (const u32 *)rowtied, (const u64 *)bval, (const u32 *)bidx, bflag, ab);
+            hipLaunchKernelGGL(k_bs, dim3(pgrid), dim3(BK_NT), BkCfg::LDS_BYTES, s, Y, n, row0, rows, NBT, (const u32 *)bcnt,
+                               (const u32 *)nnanrow, (const u32 *)bflag, (const u32 *)rowtied, (const double *)bval,
+                               (const u32 *)bidx, ab);
+            fallback_rows = ovf;                             // chunked route: only rows whose partition overflowed
+            nn_for_fold = nnanrow;
+        }
+#ifdef SD_CROSSCHECK
+        if (buckets && gen2) {
+            // ---- second generation (cross-check builds): S -> P' (or P) -> A' (or the packed-key sort) ----
+            const bool rank_nosort = xswitch("SD_BIG_SORT") != 1;
             if (NB <= 24)
                 hipLaunchKernelGGL(k_sp_small, dim3((unsigned)rows), dim3(128), lds_sp_small, s, Y, n, row0, NB, spl);
             else if (NB <= 72)
                 hipLaunchKernelGGL(k_sp, dim3((unsigned)rows), dim3(256), lds_sp, s, Y, n, row0, NB, spl);
             else
                 hipLaunchKernelGGL(k_sp_big, dim3((unsigned)rows), dim3(1024), lds_sp_big, s, Y, n, row0, NB, spl);
-#ifdef SD_CROSSCHECK
             if (xswitch("SD_BIG_PART1") == 1)                    // first-generation partition (direct scatter)
                 hipLaunchKernelGGL(bucket_partition_kernel, dim3((unsigned)((n + 16383) / 16384), (unsigned)rows), dim3(1024),
                                    0, s, Y, n, row0, NB, (const double *)spl, bcnt, nnanrow, ovf, bval, bidx, ab, 0);
             else
-#endif
                 hipLaunchKernelGGL(bucket_partition2_kernel, dim3((unsigned)((n + BP2_C - 1) / BP2_C), (unsigned)rows),
                                    dim3(BP2_NT), (size_t)BP2_C * 14, s, Y, n, row0, NB, (const double *)spl, bcnt, nnanrow,
                                    ovf, bval, bidx, ab);
-#ifdef SD_CROSSCHECK
             if (!rank_nosort)
                 hipLaunchKernelGGL(k_bp, dim3((unsigned)NB, (unsigned)rows), dim3(BK_NT), lds_bk, s, n, NB, (const u32 *)bcnt,
                                    (const u32 *)nnanrow, (const u32 *)ovf, (const double *)bval, (const u32 *)bidx, bflag, ab);
             else
-#endif
                 hipLaunchKernelGGL(k_br, dim3((unsigned)(8 * NB * ((rows + 7) / 8))), dim3(BR_NT), BR_LDS, s, n, rows, NB,
-                                   (const u32 *)bcnt,
-                                   (const u32 *)nnanrow, (const u32 *)ovf, (const double *)bval, (const u32 *)bidx, bflag, ab);
-            hipLaunchKernelGGL(k_bs, dim3((unsigned)NB, (unsigned)rows), dim3(BK_NT), BkCfg::LDS_BYTES, s, n, NB,
-                               (const u32 *)bcnt, (const u32 *)nnanrow, (const u32 *)bflag, (const double *)bval,
+                                   (const u32 *)bcnt, (const u32 *)nnanrow, (const u32 *)ovf,
+                                   (const double *)bval, (const u32 *)bidx, bflag, ab);
+            hipLaunchKernelGGL(k_bs, dim3(pgrid), dim3(BK_NT), BkCfg::LDS_BYTES, s, Y, n, row0, rows, NB, (const u32 *)bcnt,
+                               (const u32 *)nnanrow, (const u32 *)bflag, (const u32 *)nullptr, (const double *)bval,
                                (const u32 *)bidx, ab);
-            fallback_rows = ovf;                             // chunked route: only rows whose partition overflowed
+            fallback_rows = ovf;
             nn_for_fold = nnanrow;
         }
-        hipLaunchKernelGGL(k_cs, dim3((unsigned)p.nch, (unsigned)rows), dim3(BIG_NT), BigCfg::LDS_BYTES, s, Y, n, row0,
+#endif
+        // chunked route: every row (cross-check switch) or the rows whose partition overflowed (none: both launches are
+        // small persistent grids that read a few flags and leave)
+        const unsigned csgrid = fallback_rows ? pgrid : (unsigned)(p.nch * rows < 65535 * 16 ? p.nch * rows : 65535 * 16);
+        hipLaunchKernelGGL(k_cs, dim3(csgrid), dim3(BIG_NT), BigCfg::LDS_BYTES, s, Y, n, row0, rows, p.nch,
                            sorted, p.sstride, nanf, fallback_rows);
         i64 rgroups = cus / p.nch;
         if (rgroups < 1) rgroups = 1;

@@ -7,7 +7,7 @@
                  corrected as MI355X_MICROARCH.md prescribes: FETCH_SIZE x 2 on gfx950, calibrated in the same session on
                  sd::nan_count_rows_kernel (bench.py --algo pairwise), which reads the 80 000 000-byte matrix exactly once.
 
-usage: collect_profiles.py <tag>        e.g. r02
+usage: collect_profiles.py <tag> [workload ...]       e.g. r03 (everything) or r03b config3 (stats + traffic of one)
 """
 import csv
 import glob
@@ -85,10 +85,14 @@ def pmc(name):
     return res
 
 
+only = sys.argv[2:]
 for name in ("bench", "config3", "strict", "linf", "medium"):
-    stats(name)
-calib = pmc("calib")
+    if not only or name in only:
+        stats(name)
+calib = pmc("calib") if (not only or "bench" in only or "config3" in only) else {}
 for name in ("bench", "config3"):
+    if only and name not in only:
+        continue
     ks = pmc(name)
     doc = {"workload": WORKLOADS[name][1], "command": " ".join(os.path.relpath(a, root) if os.path.isabs(a) else a for a in WORKLOADS[name][0]),
            "note": WORKLOADS[name][2] + ".  rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (kernel trace only); values in KiB per "
