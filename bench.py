@@ -29,6 +29,23 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK = 8.0e12          # B/s, MI355X spec (MI355X_MICROARCH.md)
+VALU_PEAK = 256 * 4 * 16 * 2.4e9      # lane-instructions/s: 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz (one wave64 op per 4 cycles)
+
+
+def issue_roofline(key, units_per_s):
+    """Roofline object of a VALU-issue-bound kernel: lane-instructions per unit from the committed SQ counters
+    (profiles/*issue_roofline.json: SQ_INSTS_VALU x 64 / units) x the unit rate measured in this run, against the chip's vector
+    issue peak.  None when no committed counter file names the kernel."""
+    for path in reversed(sorted(glob.glob(os.path.join(ROOT, "profiles", "*issue_roofline.json")))):
+        with open(path) as f:
+            doc = json.load(f)
+        if key in doc and "valu_lane_instructions_per_unit" in doc[key]:
+            per = float(doc[key]["valu_lane_instructions_per_unit"])
+            ach = per * units_per_s
+            return {"bound": "valu", "achieved": ach / 1e12, "peak": VALU_PEAK / 1e12, "unit": "T lane-instructions/s",
+                    "frac": ach / VALU_PEAK, "traffic": None, "kernel": doc[key].get("kernel"),
+                    "lane_instructions_per_unit": per, "counter_file": os.path.relpath(path, ROOT)}
+    return None
 
 
 def pmc_traffic(kernels, n, T, J):
@@ -63,6 +80,23 @@ def profiled_kernel_us(kernel, n, T, J):
                 if kernel in row.get("Name", ""):
                     return float(row["AverageNs"]) / 1e3, os.path.relpath(path, ROOT)
     return None, None
+
+
+def strict_roofline():
+    """Issue roofline of the strict band depth's dominant kernel (strict_masks_rank_kernel: all 32-bit integer VALU) from
+    the committed SQ counters of the 10 000 x 1 000 workload (profiles/*issue_strict.json): wave-instructions per second
+    against the chip's 256 x 4 SIMDs x 2.4 GHz / 4 cycles."""
+    for path in reversed(sorted(glob.glob(os.path.join(ROOT, "profiles", "*issue_strict.json")))):
+        with open(path) as f:
+            doc = json.load(f)
+        k = doc.get("sd::strict_masks_rank_kernel")
+        if k and "valu_wave_instr_per_us" in k:
+            ach = float(k["valu_wave_instr_per_us"]) * 1e6
+            peak = VALU_PEAK / 64.0
+            return {"bound": "valu", "achieved": ach / 1e9, "peak": peak / 1e9, "unit": "G wave-instructions/s", "frac": ach / peak,
+                    "traffic": None, "kernel": "strict_masks_rank_kernel", "counter_file": os.path.relpath(path, ROOT),
+                    "note": "dominant kernel of the leg, profiled (committed counters of the same workload); the leg's ms is measured in this run"}
+    return None
 
 
 def timed(fn, steps, warmup, stream, torch, barrier=None):
@@ -114,8 +148,13 @@ def extras_single_gpu(torch, dev, stream, lib, check, ALGOS, oracle, reps=10):
         tg = np.linspace(0, n - 1, nt).astype(np.int64)
         want = oracle.mbd_counts(X.cpu().numpy(), tg, 2)
         assert (res[torch.from_numpy(tg).to(dev)].cpu().numpy() == want).all(), key
+        balg = 8.0 * T * 2 * n + 8.0 * n
         out[key] = {"workload": f"MBD J=2, {n} curves x {T} timepoints, 1 GPU", "ms": ms, "curve_pairs_per_s": rate(T, n, ms),
-                    "roofline_frac": (8.0 * T * 2 * n + 8.0 * n) / (ms * 1e-3) / HBM_PEAK, "checked_targets": int(nt)}
+                    "roofline_frac": balg / (ms * 1e-3) / HBM_PEAK, "checked_targets": int(nt),
+                    "roofline": {"bound": "hbm", "achieved": balg / (ms * 1e-3) / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                                 "frac": balg / (ms * 1e-3) / HBM_PEAK, "traffic": None, "algorithmic_bytes": balg,
+                                 "kernels_of_step": ["bucket_setup_kernel", "bucket_partition3_kernel", "bucket_rank32_kernel",
+                                                     "rank_accumulate2_kernel"]}}
         del X, res
     Xh = np.round(np.random.default_rng(1234).normal(size=(1000, 10000)).cumsum(axis=0), 1)
     dup = np.random.default_rng(7).choice(10000, size=100, replace=False)
@@ -161,7 +200,8 @@ def extras_single_gpu(torch, dev, stream, lib, check, ALGOS, oracle, reps=10):
     tg = np.array([0, 2500, 5000, 9999])
     assert (res.cpu().numpy()[tg, 0] == oracle.bd_strict_counts(Xw, tg)).all(), "strict 10000"
     out["strict_10000x1000"] = {"workload": "strict band depth J=2, 10000 random walks x 1000 timepoints, every target", "ms": ms,
-                                "pair_tests_per_s": n * (n - 1) * (n - 2) / 2 / (ms * 1e-3), "checked_targets": len(tg)}
+                                "pair_tests_per_s": n * (n - 1) * (n - 2) / 2 / (ms * 1e-3), "checked_targets": len(tg),
+                                "roofline": strict_roofline()}
     del Xd, res, ws
     # config 5 (i), the reference's default relax=False: L-infinity (box) depth of 10^6 points in R^3, every point a target
     P6 = np.random.default_rng(1237).normal(size=(1000000, 3))
@@ -222,6 +262,72 @@ def extras_single_gpu(torch, dev, stream, lib, check, ALGOS, oracle, reps=10):
                                          "(r2_enum), exact pair counts, all targets", "ms": ms,
                                          "curve_pairs_per_s": float(n4) * (n4 - 1) / (ms * 1e-3), "checked_targets": len(tg)}
     del P4, ws4
+    out.update(extras_full_size_configs(torch, dev, stream, lib, check, oracle))
+    return out
+
+
+def extras_full_size_configs(torch, dev, stream, lib, check, oracle):
+    """BASELINE.json configs 1, 4 and 5 at their stated sizes, each checked against the oracle on a
+    sample and carrying its own roofline object (VALU-issue based: these kernels are fp64-compute bound, not HBM bound)."""
+    out = {}
+    # ---- config 1: 50 curves x 100 timepoints through the DataFrame -> Series API, both relax modes, beside the
+    # reference's own time on this recipe (39.9 s / 42.5 s on one core: tests/golden g7, SURVEY.md 8(d))
+    import pandas as pd
+    from statdepth_amd import FunctionalDepth
+    X1 = np.random.default_rng(0).normal(size=(100, 50))
+    df1 = pd.DataFrame(X1)
+    for relax, ref_s in ((True, 39.9), (False, 42.5)):
+        FunctionalDepth([df1], J=2, relax=relax)                               # first call: allocations, module load
+        t1 = time.perf_counter()
+        for _ in range(5):
+            d = FunctionalDepth([df1], J=2, relax=relax)
+        ms = (time.perf_counter() - t1) / 5 * 1e3
+        want = oracle.univariate_depths(X1, None, J=2, relax=relax)
+        assert np.max(np.abs(d.to_numpy() - want)) <= 1e-12, "config 1"
+        out[f"config1_api_relax_{relax}"] = {
+            "workload": f"config 1: FunctionalDepth([50 curves x 100 timepoints DataFrame], J=2, relax={relax}) -> Series, "
+                        "host API end to end (validation, H2D, kernels, D2H, normalisation)",
+            "ms": ms, "curve_pairs_per_s": 50 * 49 / (ms * 1e-3), "reference_seconds_recorded": ref_s,
+            "speedup_vs_reference_recorded": ref_s / (ms * 1e-3), "checked_targets": 50,
+            "roofline": {"bound": "latency", "achieved": None, "peak": None, "unit": None, "frac": None, "traffic": None,
+                         "note": "40 KB of data: the call is host / launch latency, no device roof applies"}}
+    # ---- config 4 (i): 5 000 curves x 500 timepoints x 8 features, 4 096 sampled 9-point simplices per target
+    n4, T4, d4, S4 = 5000, 500, 8, 4096
+    g = torch.Generator(device=dev).manual_seed(1236)
+    C4 = torch.randn(n4, T4, d4, dtype=torch.float64, device=dev, generator=g).cumsum(1)
+    o4 = torch.empty(n4, dtype=torch.int64, device=dev)
+    _, ms = timed(lambda _: check(lib.sd_multi_simplex_sampled(C4.data_ptr(), n4, T4, d4, 0, n4, 1, 1e-7, S4, 1236, o4.data_ptr(),
+                                                              stream.cuda_stream)), 1, 0, stream, torch)
+    tg = np.array([0, 2500, 4999])
+    assert (o4.cpu().numpy()[tg] == oracle.simplex_sampled(C4.cpu().numpy(), tg, relax=True, samples=S4, seed=1236)).all(), "config 4"
+    units = float(n4) * S4 * T4
+    out["config4_sampled_simplex_full"] = {
+        "workload": "config 4 (i): 5000 curves x 500 timepoints x 8 features, 4096 sampled subsets per target (seed 1236), relax=True",
+        "ms": ms, "simplex_tests_per_s": units / (ms * 1e-3), "checked_targets": len(tg),
+        "roofline": issue_roofline("simplex8", units / (ms * 1e-3))}
+    del C4, o4
+    # ---- config 5 (ii) L1 depth and (iii) 4 096 sampled tetrahedra per point, 10^6 points in R^3
+    n5 = 1000000
+    P5 = np.random.default_rng(1237).normal(size=(n5, 3))
+    Pd = torch.from_numpy(P5).to(dev)
+    o5 = torch.empty(n5, dtype=torch.float64, device=dev)
+    _, ms = timed(lambda _: check(lib.sd_l1_depth(Pd.data_ptr(), n5, 3, 0, n5, o5.data_ptr(), stream.cuda_stream)), 1, 0, stream, torch)
+    tg = np.arange(0, n5, 62500)
+    assert np.max(np.abs(o5.cpu().numpy()[tg] - oracle.l1_depth(P5, tg))) <= 1e-12, "config 5 l1"
+    units = float(n5) * n5
+    out["config5_l1_full"] = {"workload": "config 5 (ii): L1 depth, 10^6 points in R^3, every point", "ms": ms,
+                              "point_pairs_per_s": units / (ms * 1e-3), "checked_targets": len(tg),
+                              "roofline": issue_roofline("l1", units / (ms * 1e-3))}
+    oc = torch.empty(n5, dtype=torch.int64, device=dev)
+    _, ms = timed(lambda _: check(lib.sd_pointcloud_simplex_sampled(Pd.data_ptr(), n5, 3, 0, n5, 1e-7, 4096, 1237, oc.data_ptr(),
+                                                                   stream.cuda_stream)), 2, 1, stream, torch)
+    tg = np.arange(0, n5, 10000)
+    assert (oc.cpu().numpy()[tg] == oracle.simplex_sampled(P5, tg, samples=4096, seed=1237)).all(), "config 5 simplex"
+    units = float(n5) * 4096
+    out["config5_sampled_simplex_full"] = {
+        "workload": "config 5 (iii): 10^6 points in R^3, 4096 sampled tetrahedra per point (seed 1237)", "ms": ms,
+        "simplex_tests_per_s": units / (ms * 1e-3), "checked_targets": len(tg),
+        "roofline": issue_roofline("simplex3", units / (ms * 1e-3))}
     return out
 
 

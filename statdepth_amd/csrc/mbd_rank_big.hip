@@ -26,6 +26,8 @@
 // see DESIGN.md.
 #include <stdlib.h>
 
+#include <atomic>
+
 #include "sd_common.h"
 #include "rank_sort.h"
 #include "rank_bucket.h"
@@ -63,9 +65,11 @@ using BigCfg = R2Cfg<BIG_NT, BIG_E>;
 // a few flags and leaves)
 __global__ __launch_bounds__(BIG_NT) void chunk_sort_kernel(const double *__restrict__ Y, i64 n, i64 row0, i64 rows, i64 nch,
                                                             double *__restrict__ sorted, i64 sstride,
-                                                            u32 *__restrict__ nanrow, const u32 *__restrict__ rowflag) {
+                                                            u32 *__restrict__ nanrow, const u32 *__restrict__ rowflag,
+                                                            const u32 *__restrict__ gate, u32 epoch) {
     constexpr int E = BIG_E, WB = BigCfg::WB;
     extern __shared__ double Sm[];
+    if (gate && *gate != epoch) return;                       // no row of this batch overflowed its value buckets
     for (i64 v = blockIdx.x; v < rows * nch; v += gridDim.x) {
     const i64 c = v % nch, rb = v / nch;
     if (rowflag && !rowflag[rb]) continue;
@@ -108,9 +112,10 @@ __global__ __launch_bounds__(BIG_NT) void chunk_search_kernel(const double *__re
                                                               i64 rows, const double *__restrict__ sorted,
                                                               i64 sstride, const u32 *__restrict__ nanrow,
                                                               int nchunks, const u32 *__restrict__ rowflag,
-                                                              AB2 ab) {
+                                                              const u32 *__restrict__ gate, u32 epoch, AB2 ab) {
     constexpr int E = BIG_E, WB = BigCfg::WB, N = BIG_C;
     extern __shared__ double Sm[];
+    if (gate && *gate != epoch) return;                       // no row of this batch overflowed its value buckets
     const int t = threadIdx.x;
     const int qc = (int)(blockIdx.x % nchunks);
     const int rgroups = gridDim.x / nchunks;
@@ -513,7 +518,8 @@ constexpr size_t BR_LDS = BR_HDR + (size_t)(BR_NBF / 2 + 4) * 4 + (size_t)(BK_C 
 __device__ __forceinline__ void bucket_rank_item(const int w, i64 n, i64 rows, int NB, const u32 *__restrict__ bcnt,
                                                  const u32 *__restrict__ nnanrow, const u32 *__restrict__ ovf,
                                                  const u32 *__restrict__ rowtied, const double *__restrict__ bval,
-                                                 const u32 *__restrict__ bidx, u32 *__restrict__ bflag, AB2 ab) {
+                                                 const u32 *__restrict__ bidx, u32 *__restrict__ bflag,
+                                                 u32 *__restrict__ gate, u32 epoch, AB2 ab) {
     constexpr int E = BR_E, NT = BR_NT, NBF = BR_NBF, NW = BR_NW, U2 = BR_U2;
     extern __shared__ double Sm[];
     double *red = Sm;                                                 // [NW][2]
@@ -583,12 +589,12 @@ __device__ __forceinline__ void bucket_rank_item(const int w, i64 n, i64 rows, i
 #pragma unroll
             for (int e = 0; e < E; ++e)
                 if (t + e * NT < cnt) ab_store(ab, abrow + idp[e * NT], gbase, nreal - gbase - (u32)cnt, nreal);
-        } else if (t == 0) bflag[rb * NB + b] = 1u;                   // a signalling NaN poisoned the range: sort it
+        } else if (t == 0) { bflag[rb * NB + b] = 1u; if (gate) gate[0] = epoch; }                   // a signalling NaN poisoned the range: sort it
         return;
     }
     const double scale = (double)NBF / (hi - lo);                     // infinite range -> 0 -> one crowded fine bucket
     if (!(scale < INF)) {                                             // block-uniform: denormal range
-        if (t == 0) bflag[rb * NB + b] = 1u;
+        if (t == 0) { bflag[rb * NB + b] = 1u; if (gate) gate[0] = epoch; }
         return;
     }
     // ---- (1) fine bucket + slot ----
@@ -670,7 +676,7 @@ __device__ __forceinline__ void bucket_rank_item(const int w, i64 n, i64 rows, i
             return;
         }
         if (anyover) {
-            if (t == 0) bflag[rb * NB + b] = 1u;
+            if (t == 0) { bflag[rb * NB + b] = 1u; if (gate) gate[0] = epoch; }
             return;
         }
     }
@@ -716,7 +722,7 @@ __global__ __launch_bounds__(BR_NT) void bucket_rank_kernel(i64 n, i64 rows, int
                                                             const double *__restrict__ bval,
                                                             const u32 *__restrict__ bidx, u32 *__restrict__ bflag,
                                                             AB2 ab) {
-    bucket_rank_item(blockIdx.x, n, rows, NB, bcnt, nnanrow, ovf, nullptr, bval, bidx, bflag, ab);
+    bucket_rank_item(blockIdx.x, n, rows, NB, bcnt, nnanrow, ovf, nullptr, bval, bidx, bflag, nullptr, 0u, ab);
 }
 #endif
 
@@ -887,7 +893,11 @@ __global__ __launch_bounds__(P3_NT) void bucket_partition3_kernel(const double *
                                                                   const u32 *__restrict__ rowtied,
                                                                   u32 *__restrict__ bcnt, u32 *__restrict__ nnanrow,
                                                                   u32 *__restrict__ ovf, u64 *__restrict__ rec,
-                                                                  u32 *__restrict__ bidx, AB2 ab) {
+                                                                  u32 *__restrict__ bidx, u32 *__restrict__ gate,
+                                                                  u32 epoch, AB2 ab) {
+    // One block of 4 096 curves of one row per workgroup, three workgroups per CU.  (Measured and dropped: 4 consecutive
+    // blocks per workgroup with the next block's keys prefetched and the row's table loaded once -- 95 VGPRs, two workgroups
+    // per CU, 128 us against 111 us at config 3: the third resident workgroup hides more latency than the prefetch.)
     extern __shared__ double Sm3[];
     const int NS = NBT - 1;
     u64 *stage = reinterpret_cast<u64 *>(Sm3);                         // [P3_C] records in bucket order
@@ -899,10 +909,17 @@ __global__ __launch_bounds__(P3_NT) void bucket_partition3_kernel(const double *
     u32 *s_lbase = s_gbase + NBT;                                      // [NBT + 1]
     u32 *s_wtot = s_lbase + NBT + 2;                                   // [P3_NT / 64]
     unsigned short *sbk = reinterpret_cast<unsigned short *>(s_wtot + P3_NT / 64 + 1);   // [P3_C]
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const i64 rb = blockIdx.y;
-    const i64 base = (i64)blockIdx.x * P3_C;
     const double *row = Y + (row0 + rb) * n;
+    const i64 base = (i64)blockIdx.x * P3_C;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+#ifdef SD_P3_STAGGER
+    {   // three workgroups per CU: the second and third dispatch rounds start a third / two thirds of a block late
+        const i64 lin = (i64)blockIdx.y * gridDim.x + blockIdx.x;
+        if (lin >= SD_P3_STAGGER && lin < 2 * SD_P3_STAGGER) __builtin_amdgcn_s_sleep(64);
+        if (lin >= 2 * SD_P3_STAGGER && lin < 3 * SD_P3_STAGGER) __builtin_amdgcn_s_sleep(127);
+    }
+#endif
     double x[P3_E];
 #pragma unroll
     for (int e = 0; e < P3_E; ++e) {
@@ -917,112 +934,132 @@ __global__ __launch_bounds__(P3_NT) void bucket_partition3_kernel(const double *
     }
     const double2 prm = rp[rb];
     const bool tied = rowtied[rb] != 0;                                // block-uniform
-    __syncthreads();
-    u32 bk[P3_E], off[P3_E], q[P3_E];
+    const int per = (NBT + P3_NT - 1) / P3_NT;                         // buckets per thread in the prefix phase (<= 3)
     u32 mynan = 0;
+    bool over = false;
+    __syncthreads();
+    {
+#if defined(SD_TUNING) && defined(SD_P3_STOP)
+        if (SD_P3_STOP == 1) { double a = 0; for (int e = 0; e < P3_E; ++e) a += x[e]; if (a == 1.2345e300) bidx[0] = 1; return; }
+#endif
+        u32 bk[P3_E], off[P3_E], q[P3_E];
 #pragma unroll
-    for (int e = 0; e < P3_E; ++e) {
-        const i64 i = base + t + e * P3_NT;
-        bk[e] = 0xFFFFFFFFu;
-        off[e] = 0;
-        q[e] = 0;
-        if (i < n) {
-            const double xv = x[e];
-            if (xv == xv) {
-                const u32 tb = s_tab[tb_cell(xv, prm.x, prm.y)];
-                int a = (int)(tb & 0xFFFFu), b = (int)(tb >> 16);       // bucket = number of splitters < x, in [a, b]
-                while (a < b) {
-                    const int mid = (a + b) >> 1;
-                    if (s_spl[mid] < xv) a = mid + 1;
-                    else b = mid;
-                }
-                bk[e] = (u32)a;
-                off[e] = atomicAdd(&s_hist[a], 1u);
-                if (!tied) {
-                    const double xc = xv + 0.0;
-                    u32 qq;
-                    if (a == 0) {
-                        const u32 cd = q_code(q_ord(s_spl[0]) - q_ord(xc));
-                        qq = Q_MAX - (cd < Q_MAX ? cd : Q_MAX);
-                    } else if (a == NS) {
-                        const u32 cd = q_code(q_ord(xc) - q_ord(s_spl[NS - 1]));
-                        qq = cd < Q_MAX ? cd : Q_MAX;
-                    } else {
-                        double v = (xc - s_spl[a - 1]) * s_mk[a];
-                        v = v < (double)Q_MAX ? v : (double)Q_MAX;     // NaN -> Q_MAX
-                        qq = (u32)v;
+        for (int e = 0; e < P3_E; ++e) {
+            const i64 i = base + t + e * P3_NT;
+            bk[e] = 0xFFFFFFFFu;
+            off[e] = 0;
+            q[e] = 0;
+            if (i < n) {
+                const double xv = x[e];
+                if (xv == xv) {
+                    const u32 tb = s_tab[tb_cell(xv, prm.x, prm.y)];
+                    int a = (int)(tb & 0xFFFFu), b = (int)(tb >> 16);   // bucket = number of splitters < x, in [a, b]
+                    while (a < b) {
+                        const int mid = (a + b) >> 1;
+                        if (s_spl[mid] < xv) a = mid + 1;
+                        else b = mid;
                     }
-                    q[e] = qq;
+                    bk[e] = (u32)a;
+                    off[e] = atomicAdd(&s_hist[a], 1u);
+                    if (!tied) {
+                        const double xc = xv + 0.0;
+                        u32 qq;
+                        if (a == 0) {
+                            const u32 cd = q_code(q_ord(s_spl[0]) - q_ord(xc));
+                            qq = Q_MAX - (cd < Q_MAX ? cd : Q_MAX);
+                        } else if (a == NS) {
+                            const u32 cd = q_code(q_ord(xc) - q_ord(s_spl[NS - 1]));
+                            qq = cd < Q_MAX ? cd : Q_MAX;
+                        } else {
+                            double v = (xc - s_spl[a - 1]) * s_mk[a];
+                            v = v < (double)Q_MAX ? v : (double)Q_MAX; // NaN -> Q_MAX
+                            qq = (u32)v;
+                        }
+                        q[e] = qq;
+                    }
+                } else {
+                    ++mynan;
+                    ab.B[rb * n + i] = AB2_NAN;
                 }
-            } else {
-                ++mynan;
-                ab.B[rb * n + i] = AB2_NAN;
+            }
+        }
+        __syncthreads();                                               // B1: the block's histogram is complete
+#if defined(SD_TUNING) && defined(SD_P3_STOP)
+        if (SD_P3_STOP == 2) { u32 a = 0; for (int e = 0; e < P3_E; ++e) a ^= bk[e] ^ off[e] ^ q[e]; if (a == 0x12345678u) bidx[0] = a; return; }
+#endif
+        // global base of this workgroup's run in every bucket (one returning atomic per bucket: its round trip to L2 is
+        // spent under the local prefix sum and the LDS scatter, the result is only needed for the copy-out); local exclusive
+        // prefix of the workgroup's counts.  Thread t owns the buckets [t * per, t * per + per), per <= 3.
+        u32 gb0 = 0, gb1 = 0, gb2 = 0;
+        {
+            u32 run = 0;
+            {
+                const int b = t * per;
+                if (b < NBT) { const u32 c = s_hist[b]; gb0 = c ? atomicAdd(&bcnt[rb * NBT + b], c) : 0u; run += c; }
+            }
+            if (per > 1) {
+                const int b = t * per + 1;
+                if (b < NBT) { const u32 c = s_hist[b]; gb1 = c ? atomicAdd(&bcnt[rb * NBT + b], c) : 0u; run += c; }
+            }
+            if (per > 2) {
+                const int b = t * per + 2;
+                if (b < NBT) { const u32 c = s_hist[b]; gb2 = c ? atomicAdd(&bcnt[rb * NBT + b], c) : 0u; run += c; }
+            }
+            const u32 incl = rb_wave_incl_scan(run);
+            if (lane == 63) s_wtot[wave] = incl;
+            __syncthreads();                                           // B2
+            u32 o = incl - run;
+            for (int w = 0; w < wave; ++w) o += s_wtot[w];
+            for (int r = 0; r < per; ++r) {
+                const int b = t * per + r;
+                if (b < NBT) {
+                    s_lbase[b] = o;
+                    o += s_hist[b];
+                }
+            }
+            if (t == P3_NT - 1) s_lbase[NBT] = o;                       // non-NaN keys of the block
+        }
+        __syncthreads();                                               // B3
+#pragma unroll
+        for (int e = 0; e < P3_E; ++e) {
+            if (bk[e] != 0xFFFFFFFFu) {
+                const u32 lp = s_lbase[bk[e]] + off[e];
+                const u32 id = (u32)(base + t + e * P3_NT);
+                stage[lp] = tied ? (u64)__double_as_longlong(x[e]) : ((u64)q[e] | ((u64)id << 32));
+                sbk[lp] = (unsigned short)bk[e];
+            }
+        }
+        if (t * per < NBT) s_gbase[t * per] = gb0;
+        if (per > 1 && t * per + 1 < NBT) s_gbase[t * per + 1] = gb1;
+        if (per > 2 && t * per + 2 < NBT) s_gbase[t * per + 2] = gb2;
+        __syncthreads();                                               // B4
+#if defined(SD_TUNING) && defined(SD_P3_STOP)
+        if (SD_P3_STOP == 4) { if (stage[t] == 0x123456789ull && s_gbase[0] == 77u) bidx[0] = 1; return; }
+#endif
+        const u32 nval = s_lbase[NBT];
+        for (u32 p = t; p < nval; p += P3_NT) {
+            const u32 b = sbk[p];
+            const u32 g = s_gbase[b] + (p - s_lbase[b]);
+            if (g < (u32)BK_C) rec[((size_t)rb * NBT + b) * BK_C + g] = stage[p];
+            else over = true;
+        }
+        if (tied) {                                                    // fp64 records: the curve indices in a second round
+            __syncthreads();
+            u32 *stage32 = reinterpret_cast<u32 *>(stage);
+#pragma unroll
+            for (int e = 0; e < P3_E; ++e)
+                if (bk[e] != 0xFFFFFFFFu) stage32[s_lbase[bk[e]] + off[e]] = (u32)(base + t + e * P3_NT);
+            __syncthreads();
+            for (u32 p = t; p < nval; p += P3_NT) {
+                const u32 b = sbk[p];
+                const u32 g = s_gbase[b] + (p - s_lbase[b]);
+                if (g < (u32)BK_C) bidx[((size_t)rb * NBT + b) * BK_C + g] = stage32[p];
             }
         }
     }
     for (int o = 32; o > 0; o >>= 1) mynan += __shfl_down(mynan, o);
     if (lane == 0 && mynan) atomicAdd(&nnanrow[rb], mynan);
-    __syncthreads();
-    // global base of this workgroup's run in every bucket; local exclusive prefix of its counts.  Thread t owns the
-    // buckets [t * per, t * per + per).
-    {
-        const int per = (NBT + P3_NT - 1) / P3_NT;                     // <= 3
-        u32 run = 0;
-        for (int r = 0; r < per; ++r) {
-            const int b = t * per + r;
-            if (b < NBT) {
-                const u32 c = s_hist[b];
-                s_gbase[b] = c ? atomicAdd(&bcnt[rb * NBT + b], c) : 0u;
-                run += c;
-            }
-        }
-        const u32 incl = rb_wave_incl_scan(run);
-        if (lane == 63) s_wtot[wave] = incl;
-        __syncthreads();
-        u32 o = incl - run;
-        for (int w = 0; w < wave; ++w) o += s_wtot[w];
-        for (int r = 0; r < per; ++r) {
-            const int b = t * per + r;
-            if (b < NBT) {
-                s_lbase[b] = o;
-                o += s_hist[b];
-            }
-        }
-        if (t == P3_NT - 1) s_lbase[NBT] = o;                           // non-NaN keys of the block
-    }
-    __syncthreads();
-#pragma unroll
-    for (int e = 0; e < P3_E; ++e) {
-        if (bk[e] != 0xFFFFFFFFu) {
-            const u32 lp = s_lbase[bk[e]] + off[e];
-            const u32 id = (u32)(base + t + e * P3_NT);
-            stage[lp] = tied ? (u64)__double_as_longlong(x[e]) : ((u64)q[e] | ((u64)id << 32));
-            sbk[lp] = (unsigned short)bk[e];
-        }
-    }
-    __syncthreads();
-    const u32 nval = s_lbase[NBT];
-    bool over = false;
-    for (u32 p = t; p < nval; p += P3_NT) {
-        const u32 b = sbk[p];
-        const u32 g = s_gbase[b] + (p - s_lbase[b]);
-        if (g < (u32)BK_C) rec[((size_t)rb * NBT + b) * BK_C + g] = stage[p];
-        else over = true;
-    }
-    if (over) ovf[rb] = 1u;
-    if (tied) {                                                        // fp64 records: the curve indices in a second round
-        __syncthreads();
-        u32 *stage32 = reinterpret_cast<u32 *>(stage);
-#pragma unroll
-        for (int e = 0; e < P3_E; ++e)
-            if (bk[e] != 0xFFFFFFFFu) stage32[s_lbase[bk[e]] + off[e]] = (u32)(base + t + e * P3_NT);
-        __syncthreads();
-        for (u32 p = t; p < nval; p += P3_NT) {
-            const u32 b = sbk[p];
-            const u32 g = s_gbase[b] + (p - s_lbase[b]);
-            if (g < (u32)BK_C) bidx[((size_t)rb * NBT + b) * BK_C + g] = stage32[p];
-        }
-    }
+    if (over) { ovf[rb] = 1u; gate[1] = epoch; }                       // a gate word is "set" when it holds the batch's epoch
 }
 
 // A3: grid = 8 * NBT * ceil(rows / 8) (the XCD-aware mapping of bucket_rank_kernel), 512 threads x 16 keys
@@ -1032,16 +1069,22 @@ static_assert(A3_NT * A3_E == BK_C, "one thread slot per key of a full value buc
 static_assert(A3_NBF / 2 / A3_NT == 4, "one 16-byte quad of histogram words per thread");
 constexpr size_t A3_HDR = 256;
 constexpr size_t A3_LDS32 = A3_HDR + (size_t)(A3_NBF / 2 + 4) * 4 + (size_t)(BK_C + A3_PAD) * 4 + (size_t)(BK_C + A3_PAD) * 2;
+#if defined(SD_TUNING) && defined(SD_A3_EXP)
+constexpr size_t A3_LDS = A3_HDR + (size_t)(A3_NBF / 2 + 4) * 4 + (size_t)(BK_C + A3_PAD) * 4 + 64;   // timing experiment: no Jx, no tied path
+#define SD_A3_ATTR __attribute__((amdgpu_waves_per_eu(SD_A3_EXP, SD_A3_EXP)))
+#else
 constexpr size_t A3_LDS = A3_LDS32 > BR_LDS ? A3_LDS32 : BR_LDS;      // rows flagged "tied" run A' inside this kernel
+#define SD_A3_ATTR
+#endif
 
-__global__ __launch_bounds__(A3_NT) void bucket_rank32_kernel(const double *__restrict__ Y, i64 n, i64 row0, i64 rows, int NBT,
+__global__ __launch_bounds__(A3_NT) SD_A3_ATTR void bucket_rank32_kernel(const double *__restrict__ Y, i64 n, i64 row0, i64 rows, int NBT,
                                                               const u32 *__restrict__ bcnt,
                                                               const u32 *__restrict__ nnanrow,
                                                               const u32 *__restrict__ ovf,
                                                               const u32 *__restrict__ rowtied,
                                                               const u64 *__restrict__ rec,
                                                               const u32 *__restrict__ bidx, u32 *__restrict__ bflag,
-                                                              AB2 ab) {
+                                                              u32 *__restrict__ gate, u32 epoch, AB2 ab) {
     constexpr int E = A3_E, NT = A3_NT, NBF = A3_NBF, NW = A3_NW, U = A3_U;
     extern __shared__ double Sm[];
     u32 *red = reinterpret_cast<u32 *>(Sm);                            // [NW][2] min / max, then [NW] earlier-bucket sums
@@ -1053,14 +1096,26 @@ __global__ __launch_bounds__(A3_NT) void bucket_rank32_kernel(const double *__re
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int w = blockIdx.x;
+#ifdef SD_A3_STAGGER
+    // Two workgroups share a CU and would run their load / LDS / store phases in lock-step (the phase times of the kernel add
+    // up: profiles/r03e_phase_times_config3.txt).  The workgroups of the second dispatch round start half an item late;
+    // their successors inherit the offset.
+    if (w >= SD_A3_STAGGER && w < 2 * SD_A3_STAGGER) {
+        __builtin_amdgcn_s_sleep(127);
+        __builtin_amdgcn_s_sleep(127);
+    }
+#endif
     const int b = (w >> 3) % NBT;
     const i64 rb = (i64)((w >> 3) / NBT) * 8 + (w & 7);
     if (rb >= rows) return;
     if (ovf[rb]) return;
+#if !(defined(SD_TUNING) && defined(SD_A3_EXP))
     if (rowtied[rb]) {                                                // block-uniform: fp64 records, A' (same LDS, same grid)
-        bucket_rank_item(w, n, rows, NBT, bcnt, nnanrow, ovf, rowtied, reinterpret_cast<const double *>(rec), bidx, bflag, ab);
+        bucket_rank_item(w, n, rows, NBT, bcnt, nnanrow, ovf, rowtied, reinterpret_cast<const double *>(rec), bidx, bflag,
+                         gate, epoch, ab);
         return;
     }
+#endif
     const u32 *rowcnt = bcnt + rb * NBT;
     const int cnt = (int)rowcnt[b];
     if (cnt == 0) return;
@@ -1094,6 +1149,9 @@ __global__ __launch_bounds__(A3_NT) void bucket_rank32_kernel(const double *__re
     mx = rb_wave_allreduce_u32<true>(mx);
     if (lane == 63) { red[2 * wave] = mn; red[2 * wave + 1] = mx; wtot[wave] = gsum; }
     __syncthreads();                                                  // barrier 1
+#if defined(SD_TUNING) && defined(SD_A3_STOP)
+    if (SD_A3_STOP == 1) { if (mn + gsum == 0x12345678u) ab.B[0] = mn; return; }   // timing experiment (results invalid)
+#endif
     u32 lo, hi, gbase;
     {
         const uint2 pmm = reinterpret_cast<const uint2 *>(red)[lane & (NW - 1)];
@@ -1118,6 +1176,9 @@ __global__ __launch_bounds__(A3_NT) void bucket_rank32_kernel(const double *__re
         bs[e] = fb | (((old >> sh) & 0xFFFFu) << 16);
     }
     __syncthreads();                                                  // barrier 2
+#if defined(SD_TUNING) && defined(SD_A3_STOP)
+    if (SD_A3_STOP == 2) { u32 a = 0; for (int e = 0; e < E; ++e) a ^= bs[e]; if (a == 0x12345678u) ab.B[0] = a; return; }
+#endif
     // ---- (2) exclusive prefix sum; a fine bucket above A3_CAP keys: the search kernel takes the value bucket ----
     bool anyover = false;
     {
@@ -1147,10 +1208,13 @@ __global__ __launch_bounds__(A3_NT) void bucket_rank32_kernel(const double *__re
         if (t == NT - 1) H[NBF / 2] = base;                           // = cnt
     }
     if (anyover) {                                                    // heavy ties the sample did not show
-        if (t == 0) bflag[rb * NBT + b] = 1u;
+        if (t == 0) { bflag[rb * NBT + b] = 1u; gate[0] = epoch; }
         return;
     }
     __syncthreads();                                                  // barrier 4
+#if defined(SD_TUNING) && defined(SD_A3_STOP)
+    if (SD_A3_STOP == 3) { u32 a = H[t]; for (int e = 0; e < E; ++e) a ^= bs[e]; if (a == 0x12345678u) ab.B[0] = a; return; }
+#endif
     // ---- (3) scatter into fine-bucket order ----
     u32 bc[E];                                                        // base | count << 16; count 0: no key
     const u32 dummy = (u32)(cnt + A3_PAD - 1);
@@ -1162,10 +1226,15 @@ __global__ __launch_bounds__(A3_NT) void bucket_rank32_kernel(const double *__re
         const bool isk = fb < (u32)NBF;
         const u32 pos = isk ? base + slot : dummy;
         S[pos] = isk ? q[e] : 0xFFFFFFFFu;
+#if !(defined(SD_TUNING) && defined(SD_A3_EXP))
         Jx[pos] = (unsigned short)(t + e * NT);
+#endif
         bc[e] = isk ? (base | ((end - base) << 16)) : 0u;
     }
     __syncthreads();                                                  // barrier 5
+#if defined(SD_TUNING) && defined(SD_A3_STOP)
+    if (SD_A3_STOP == 4) { u32 a = S[t]; for (int e = 0; e < E; ++e) a ^= bc[e] ^ id[e]; if (a == 0x12345678u) ab.B[0] = a; return; }
+#endif
     // ---- (4) rank inside the fine bucket, write B ----
     const double *yrow = Y + (row0 + rb) * n;
 #pragma unroll
@@ -1193,6 +1262,9 @@ __global__ __launch_bounds__(A3_NT) void bucket_rank32_kernel(const double *__re
         less -= offq;                                                 // keys in front of the base: earlier fine buckets, all smaller
         if (fc) {
             if (eq == 1u) {
+#if defined(SD_TUNING) && defined(SD_A3_STOP)
+                if (SD_A3_STOP == 5) { if (gbase + base + less == 0xFFFFFFF0u) ab.B[abrow + id[e]] = 1; } else     // no store
+#endif
                 ab.B[abrow + id[e]] = gbase + base + less;            // untied: A = nreal - 1 - B
             } else {
                 // another member carries the same image: the fp64 values of those members decide
@@ -1200,7 +1272,11 @@ __global__ __launch_bounds__(A3_NT) void bucket_rank32_kernel(const double *__re
                 u32 lt = 0, eqv = 0;
                 for (u32 m = base; m < base + fc; ++m) {
                     if (S[m] == x) {
+#if defined(SD_TUNING) && defined(SD_A3_EXP)
+                        const u32 im = id[e];                          // timing experiment: no partner look-up (results invalid)
+#else
                         const u32 im = (u32)(rec[slot0 + Jx[m]] >> 32);
+#endif
                         const double yv = yrow[im];
                         lt += (yv < xv) ? 1u : 0u;
                         eqv += (yv == xv) ? 1u : 0u;
@@ -1222,11 +1298,13 @@ __global__ __launch_bounds__(BK_NT) void bucket_search_kernel(const double *__re
                                                               const u32 *__restrict__ bflag,
                                                               const u32 *__restrict__ rowtied,
                                                               const double *__restrict__ bval,
-                                                              const u32 *__restrict__ bidx, AB2 ab) {
+                                                              const u32 *__restrict__ bidx,
+                                                              const u32 *__restrict__ gate, u32 epoch, AB2 ab) {
     using C = BkCfg;
     constexpr int E = BK_E, NT = BK_NT, LE = C::LE, WB = C::WB, N = C::N;
     extern __shared__ double Sm[];
     __shared__ u32 s_basecnt;
+    if (gate && *gate != epoch) return;                               // no bucket of this batch was flagged
     const u64 *rec = reinterpret_cast<const u64 *>(bval);
     for (i64 v = blockIdx.x; v < rows * NB; v += gridDim.x) {
         if (!bflag[v]) continue;                                      // block-uniform
@@ -1301,6 +1379,10 @@ __global__ __launch_bounds__(1024) void rank_accumulate2_kernel(AB2 ab, const u3
         auto fold = [&](u32 w, u32 nn, i64 row) {
             if (w == AB2_NAN) return;
             const u32 B = w & ~AB2_TIE;
+            if (J == 2 && nn == 0 && !(w & AB2_TIE)) {                // untied key of a NaN-free row: contained = A * B
+                acc[0] += (u64)B * (u64)((u32)n - 1u - B);
+                return;
+            }
             const u32 A = (w & AB2_TIE) ? ab.A[row * n + i] : (u32)n - nn - 1u - B;     // tied keys carry their A
             band_counts_add<J>(A, B, nn, (u64)(n - 1), acc);
         };
@@ -1331,6 +1413,70 @@ __global__ __launch_bounds__(1024) void rank_accumulate2_kernel(AB2 ab, const u3
     }
 }
 
+// The same fold for a contiguous, 4-aligned block of targets (the usual call: every curve): a thread takes FOUR neighbouring
+// curves through 16-byte loads, so half a wave reads 512 bytes of a row instead of 128.  block = 32 quads x 16 row slices;
+// needs n % 4 == 0 and tbegin % 4 == 0 (the image rows stay 16-byte aligned).  J <= 3 (accumulators in registers).
+template <int J>
+__global__ __launch_bounds__(512) void rank_accumulate2x4_kernel(AB2 ab, const u32 *__restrict__ nnan, i64 rows, i64 n,
+                                                                  i64 tbegin, i64 m, u64 *__restrict__ out, int first) {
+    __shared__ u64 red[16][32];
+    const int x = threadIdx.x & 31, y = threadIdx.x >> 5;
+    const i64 q0 = ((i64)blockIdx.x * 32 + x) * 4;                    // first of this thread's four targets
+    const i64 i0 = tbegin + q0;
+    u64 acc[4][JMAX - 1];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int j = 0; j < JMAX - 1; ++j) acc[c][j] = 0;
+    if (q0 < m) {
+        auto fold4 = [&](const uint4 w, u32 nn, i64 row) {
+            const u32 ww[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                if (ww[c] == AB2_NAN) continue;
+                const u32 B = ww[c] & ~AB2_TIE;
+                if (J == 2 && nn == 0 && !(ww[c] & AB2_TIE)) {
+                    // untied key of a NaN-free row: A + B = n - 1, and C(A+B, 2) - C(A, 2) - C(B, 2) = A * B
+                    acc[c][0] += (u64)B * (u64)((u32)n - 1u - B);
+                    continue;
+                }
+                const u32 A = (ww[c] & AB2_TIE) ? ab.A[row * n + i0 + c] : (u32)n - nn - 1u - B;
+                band_counts_add<J>(A, B, nn, (u64)(n - 1), acc[c]);
+            }
+        };
+        const uint4 *img = reinterpret_cast<const uint4 *>(ab.B);
+        i64 r = y;
+        for (; r + 16 * 3 < rows; r += 16 * 4) {
+            uint4 w[4];
+            u32 nn[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                w[u] = img[((r + 16 * u) * n + i0) >> 2];
+                nn[u] = nnan[r + 16 * u];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) fold4(w[u], nn[u], r + 16 * u);
+        }
+        for (; r < rows; r += 16) fold4(img[(r * n + i0) >> 2], nnan[r], r);
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+#pragma unroll
+        for (int j = 0; j < J - 1; ++j) {
+            red[y][x] = acc[c][j];
+            __syncthreads();
+            if (y == 0 && q0 + c < m) {
+                u64 tot = 0;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) tot += red[k][x];
+                if (first) out[(q0 + c) * (J - 1) + j] = tot;
+                else out[(q0 + c) * (J - 1) + j] += tot;
+            }
+            __syncthreads();
+        }
+    }
+}
+
 // =====================================================================================================
 // host side
 // =====================================================================================================
@@ -1341,7 +1487,7 @@ struct BigPlan {
     int NB, NBT;                                         // interior value buckets; NBT = NB + 2 with the two end buckets
     size_t off_ab, off_sorted, off_bval, off_bidx, off_spl, off_mk, off_tab, off_rp, off_zero, zero_bytes, total;
     // zeroed block: bcnt[rpb*NBT] | nnanrow[rpb] | ovf[rpb] | bflag[rpb*NBT] | nanrow_f[rpb] | rowtied[rpb]
-    size_t z_bcnt, z_nnan, z_ovf, z_bflag, z_nanf, z_tied;
+    size_t z_bcnt, z_nnan, z_ovf, z_bflag, z_nanf, z_tied, z_gate;
 };
 
 static BigPlan big_plan(i64 T, i64 n) {
@@ -1378,6 +1524,7 @@ static BigPlan big_plan(i64 T, i64 n) {
     p.z_bflag = ztake((size_t)r * p.NBT * 4);
     p.z_nanf = ztake((size_t)r * 4);
     p.z_tied = ztake((size_t)r * 4);
+    p.z_gate = ztake(16 * 4);                                // per batch: [0] some bucket flagged, [1] some row overflowed
     p.zero_bytes = z;
     p.total = o + z + 256;
     return p;
@@ -1413,6 +1560,10 @@ int launch_mbd_rank_big(const double *Y, i64 T, i64 n, const i64 *targets, i64 t
     char *zb = w + p.off_zero;
     u32 *bcnt = (u32 *)(zb + p.z_bcnt), *nnanrow = (u32 *)(zb + p.z_nnan), *ovf = (u32 *)(zb + p.z_ovf);
     u32 *bflag = (u32 *)(zb + p.z_bflag), *nanf = (u32 *)(zb + p.z_nanf), *rowtied = (u32 *)(zb + p.z_tied);
+    u32 *gate = (u32 *)(zb + p.z_gate);
+    // A gate word is "set" when it holds the batch's epoch (a process-wide counter, never 0): nothing has to zero it, and
+    // stale workspace contents can at worst make a fallback kernel scan flags that S3 has zeroed -- time, never results.
+    static std::atomic<u32> epoch_counter{0};
 
     const bool buckets = xswitch("SD_BIG_IMPL") != 1;       // cross-check builds, 1: chunked route for every row
 #ifdef SD_CROSSCHECK
@@ -1426,7 +1577,7 @@ int launch_mbd_rank_big(const double *Y, i64 T, i64 n, const i64 *targets, i64 t
         int v = 0;
         if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
     }
-    const unsigned pgrid = (unsigned)(2 * cus);             // small persistent grids (a multiple of 8: XCD mapping)
+    const unsigned pgrid = (unsigned)cus;                   // small persistent grids of the fallback kernels
     auto k_cs = chunk_sort_kernel;
     auto k_cq = chunk_search_kernel;
     // sample per row: 2 048 values up to 24 value buckets (>= 85 samples per bucket), 4 096 up to 72, 16 384 above.
@@ -1467,6 +1618,9 @@ int launch_mbd_rank_big(const double *Y, i64 T, i64 n, const i64 *targets, i64 t
         const i64 rows = T - row0 < p.rpb ? T - row0 : p.rpb;
         const u32 *fallback_rows = nullptr;                  // chunked route: every row
         const u32 *nn_for_fold = nanf;
+        const u32 *gate_o = nullptr;                         // no gate: the chunk kernels look at every row flag
+        u32 epoch = ++epoch_counter;
+        if (epoch == 0) epoch = ++epoch_counter;
         if (!buckets || gen2) SD_HIP(hipMemsetAsync(zb, 0, p.zero_bytes, s));      // (the third generation's S3 zeroes)
         if (buckets && !gen2) {
             // ---- third generation: S3 -> P3 -> A3 (untied rows) / A' (tied rows) ----
@@ -1481,15 +1635,16 @@ int launch_mbd_rank_big(const double *Y, i64 T, i64 n, const i64 *targets, i64 t
                                    rp, rowtied, bcnt, bflag, nnanrow, ovf, nanf);
             hipLaunchKernelGGL(bucket_partition3_kernel, dim3((unsigned)((n + P3_C - 1) / P3_C), (unsigned)rows), dim3(P3_NT),
                                lds_p3, s, Y, n, row0, NBT, (const double *)spl, (const double *)mk, (const u32 *)tab,
-                               (const double2 *)rp, (const u32 *)rowtied, bcnt, nnanrow, ovf, (u64 *)bval, bidx, ab);
+                               (const double2 *)rp, (const u32 *)rowtied, bcnt, nnanrow, ovf, (u64 *)bval, bidx, gate, epoch, ab);
             hipLaunchKernelGGL(bucket_rank32_kernel, dim3((unsigned)(8 * NBT * ((rows + 7) / 8))), dim3(A3_NT), A3_LDS, s, Y, n,
                                row0, rows, NBT, (const u32 *)bcnt, (const u32 *)nnanrow, (const u32 *)ovf,
-                               (const u32 *)rowtied, (const u64 *)bval, (const u32 *)bidx, bflag, ab);
+                               (const u32 *)rowtied, (const u64 *)bval, (const u32 *)bidx, bflag, gate, epoch, ab);
             hipLaunchKernelGGL(k_bs, dim3(pgrid), dim3(BK_NT), BkCfg::LDS_BYTES, s, Y, n, row0, rows, NBT, (const u32 *)bcnt,
                                (const u32 *)nnanrow, (const u32 *)bflag, (const u32 *)rowtied, (const double *)bval,
-                               (const u32 *)bidx, ab);
+                               (const u32 *)bidx, (const u32 *)gate, epoch, ab);
             fallback_rows = ovf;                             // chunked route: only rows whose partition overflowed
             nn_for_fold = nnanrow;
+            gate_o = gate + 1;
         }
 #ifdef SD_CROSSCHECK
         if (buckets && gen2) {
@@ -1517,7 +1672,7 @@ int launch_mbd_rank_big(const double *Y, i64 T, i64 n, const i64 *targets, i64 t
                                    (const double *)bval, (const u32 *)bidx, bflag, ab);
             hipLaunchKernelGGL(k_bs, dim3(pgrid), dim3(BK_NT), BkCfg::LDS_BYTES, s, Y, n, row0, rows, NB, (const u32 *)bcnt,
                                (const u32 *)nnanrow, (const u32 *)bflag, (const u32 *)nullptr, (const double *)bval,
-                               (const u32 *)bidx, ab);
+                               (const u32 *)bidx, (const u32 *)nullptr, 0u, ab);
             fallback_rows = ovf;
             nn_for_fold = nnanrow;
         }
@@ -1526,17 +1681,23 @@ int launch_mbd_rank_big(const double *Y, i64 T, i64 n, const i64 *targets, i64 t
         // small persistent grids that read a few flags and leave)
         const unsigned csgrid = fallback_rows ? pgrid : (unsigned)(p.nch * rows < 65535 * 16 ? p.nch * rows : 65535 * 16);
         hipLaunchKernelGGL(k_cs, dim3(csgrid), dim3(BIG_NT), BigCfg::LDS_BYTES, s, Y, n, row0, rows, p.nch,
-                           sorted, p.sstride, nanf, fallback_rows);
+                           sorted, p.sstride, nanf, fallback_rows, gate_o, epoch);
         i64 rgroups = cus / p.nch;
         if (rgroups < 1) rgroups = 1;
         if (rgroups > rows) rgroups = rows;
         hipLaunchKernelGGL(k_cq, dim3((unsigned)(rgroups * p.nch)), dim3(BIG_NT), BigCfg::LDS_BYTES, s, Y, n, row0, rows,
-                           (const double *)sorted, p.sstride, (const u32 *)nanf, (int)p.nch, fallback_rows, ab);
+                           (const double *)sorted, p.sstride, (const u32 *)nanf, (int)p.nch, fallback_rows, gate_o, epoch, ab);
         SD_HIP(hipGetLastError());
         const int first = row0 == 0;
-        dim3 grid((unsigned)((m + 63) / 64));
-        SD_DISPATCH_J(J, hipLaunchKernelGGL((rank_accumulate2_kernel<J_>), grid, dim3(1024), 0, s, ab,
-                                            nn_for_fold, rows, n, targets, tbegin, m, out, first));
+        if (!targets && (n & 3) == 0 && (tbegin & 3) == 0 && J <= 3) {
+            dim3 grid4((unsigned)((m + 127) / 128));
+            if (J == 2) hipLaunchKernelGGL((rank_accumulate2x4_kernel<2>), grid4, dim3(512), 0, s, ab, nn_for_fold, rows, n, tbegin, m, out, first);
+            else hipLaunchKernelGGL((rank_accumulate2x4_kernel<3>), grid4, dim3(512), 0, s, ab, nn_for_fold, rows, n, tbegin, m, out, first);
+        } else {
+            dim3 grid((unsigned)((m + 63) / 64));
+            SD_DISPATCH_J(J, hipLaunchKernelGGL((rank_accumulate2_kernel<J_>), grid, dim3(1024), 0, s, ab,
+                                                nn_for_fold, rows, n, targets, tbegin, m, out, first));
+        }
         SD_HIP(hipGetLastError());
     }
     return SD_OK;
