@@ -547,6 +547,9 @@ def main():
         used = "rank" if (args.algo == "rank" or (args.algo == "auto" and J <= 3)) else "pairwise"
         if used == "pairwise":
             kerns = ["mbd_pairwise_kernel"]
+        elif 4096 < n <= 11264 and J == 2 and n % 4 == 0 and n_loc == n and 256 <= T <= 4096:
+            # two launches: 32-bit key images, two workgroups per CU; then rank_bucket_kernel's SEL form (finalize + flagged rows)
+            kerns = ["rank_bucket32_kernel", "rank_bucket_kernel"]
         elif n <= 16384:
             kerns = ["rank_bucket_kernel", "rank_finalize"]
         else:

@@ -403,6 +403,8 @@ size_t mbd_rank_bucket_workspace_bytes(i64 rows, i64 n, int J);
 int launch_rank_bucket(const double *Y, i64 n, i64 row0, i64 rows, int J, u64 *partial, int *p32_out, int *G_out,
                        hipStream_t s);
 int launch_rank_bucket_image(const double *Y, i64 n, i64 row0, i64 rows, u32 *AB, u32 *nnan, hipStream_t s);
+bool rank_bucket_two_level_supported(i64 n, i64 rows);
+int launch_rank_bucket_two_level(const double *Y, i64 n, i64 row0, i64 rows, u64 *partial, u64 *out, int first, hipStream_t s);
 int launch_rank_finalize(const u64 *partial, int G, int p32, const u32 *AB, const u32 *nnan, const unsigned char *rowflag,
                          i64 rows, i64 n, const i64 *targets, i64 tbegin, i64 m, int J, u64 *out, int first,
                          hipStream_t s);
@@ -488,6 +490,11 @@ int launch_mbd_rank(const double *Y, i64 T, i64 n, const i64 *targets, i64 tbegi
         for (i64 row0 = 0; row0 < T; row0 += rpb) {
             const i64 rows = T - row0 < rpb ? T - row0 : rpb;
             int rc, G = 0, p32 = 0;
+            if (J == 2 && !targets && tbegin == 0 && m == n && rank_bucket_two_level_supported(n, rows)) {
+                // 32-bit key images, two workgroups per CU; the second launch finalizes (and ranks what the first flagged)
+                if ((rc = launch_rank_bucket_two_level(Y, n, row0, rows, partial, out, row0 == 0, s))) return rc;
+                continue;
+            }
             if ((rc = launch_rank_bucket(Y, n, row0, rows, J, partial, &p32, &G, s))) return rc;
             if ((rc = launch_rank_finalize(partial, G, p32, nullptr, nullptr, nullptr, rows, n, targets, tbegin, m, J, out,
                                            row0 == 0, s)))

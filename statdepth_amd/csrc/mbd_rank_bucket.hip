@@ -133,8 +133,8 @@ struct RBCfg {
     static constexpr int W = NB / 2 / NT;                       // histogram words per thread in the prefix sum
     static constexpr int QW = W / 4;                            // ... as 16-byte quads
     static_assert(W >= 4 && W % 4 == 0, "whole quads of histogram words per thread");
-    static_assert(NW == 16, "cross-wave reductions are laid out for 16 waves");
-    static_assert(NT == RB_SNT, "rb_slow_row is compiled for this workgroup size");
+    static_assert(NW == 16 || NW == 8, "cross-wave reductions are laid out for rows of 16 lanes");
+    static_assert(NT == RB_SNT || NT == 512, "rb_slow_row is compiled for 1024 threads (512: two workgroups per CU, no cold path)");
     // positions: [0, n) keys, [n, n + RB_PAD) sentinels, DUMMY.. a scratch pair range for keys that are NaN
     static __host__ __device__ constexpr int dummy_pos(int n) { return (n + RB_PAD + 1) & ~1; }
     static __host__ __device__ constexpr size_t keys_slots(int n) { return (size_t)dummy_pos(n) + 2 * U2 + 2; }
@@ -143,16 +143,26 @@ struct RBCfg {
     static __host__ __device__ constexpr size_t lds_bytes(int n) {
         const size_t a = keys_slots(n) * 8 + (size_t)(NB / 2 + 4) * 4;
         const size_t n_act = (size_t)((n + 1023) / 1024) * 1024;
-        const size_t b = (n_act + n_act / 16) * 8;                     // sort image of rb_slow_row (R2Cfg<1024,16> slots)
+        const size_t b = NT == RB_SNT ? (n_act + n_act / 16) * 8 : 0;  // sort image of rb_slow_row (R2Cfg<1024,16> slots)
         return HDR + (a > b ? a : b);
     }
 };
 
 // DBG (timing experiments only; 1-4: results invalid): 1 = stop after the range, 2 = after the histogram, 3 = after the
 // prefix sum, 4 = after the scatter; 5 = full kernel with cycle stamps per phase printed by wave 0 of workgroup 0
-template <int NT, int E, int LNB, int J, int CAP, int U2, int DBG = 0, bool A32 = false>
-__global__ __launch_bounds__(NT, RB_WAVES_PER_EU(E)) void rank_bucket_kernel(const double *__restrict__ Y, i64 n64, i64 row0, i64 rows,
-                                                         u64 *__restrict__ partial, int p32, u32 *__restrict__ nnan_img) {
+// SEL (J == 2, every curve a target): the second and last launch behind rank_bucket32_kernel (mbd_rank_bucket32.hip).
+// (1) Each workgroup sums its slice of curves over that kernel's Gsum u32 partial blocks and adds the totals to out_tot
+// (zeroed by rank_bucket32_kernel) -- the finalize step, without a launch of its own.  (2) Only when that kernel flagged
+// rows (*gate == epoch; else return): the flagged rows are ranked here in fp64 and their band counts added to out_tot
+// as well.  Every workgroup derives the same ordered list of flagged rows and takes entries g, g + G, ...
+template <int NT, int E, int LNB, int J, int CAP, int U2, int DBG = 0, bool A32 = false, bool SEL = false>
+__global__ __launch_bounds__(NT, (NT == 512 ? 4 : RB_WAVES_PER_EU(E))) void rank_bucket_kernel(const double *__restrict__ Y, i64 n64, i64 row0, i64 rows,
+                                                         u64 *__restrict__ partial, int p32, u32 *__restrict__ nnan_img,
+                                                         const unsigned char *__restrict__ rowflag = nullptr,
+                                                         const u32 *__restrict__ gate = nullptr, u32 epoch = 0,
+                                                         u64 *__restrict__ out_tot = nullptr, int Gsum = 0,
+                                                         const u32 *__restrict__ listbuf = nullptr,
+                                                         u32 *__restrict__ fblocks = nullptr, u32 *__restrict__ done = nullptr) {
     // J == 0: image mode (J >= 4 on the host side): no fold, the pairs (B | A << 16) of every (row, curve) go to the
     // pair image `partial` (as u32[rows][n]) and the rows' NaN counts to nnan_img; rank_accumulate*_kernel folds them
     using C = RBCfg<NT, E, LNB, U2>;
@@ -178,6 +188,87 @@ __global__ __launch_bounds__(NT, RB_WAVES_PER_EU(E)) void rank_bucket_kernel(con
     const int DUMMY = C::dummy_pos(n);
     const double2 *NANP = reinterpret_cast<const double2 *>(S + ((n + 1) & ~1));   // two of the sentinels, 16-byte aligned
     int t = t0;
+    // SEL: the ordered list of flagged rows behind everything else in LDS (u16 row indices, rows <= 4096)
+    const unsigned short *sel = reinterpret_cast<const unsigned short *>(reinterpret_cast<const char *>(Sm) + C::lds_bytes(n));
+    if constexpr (SEL) {
+        static_assert(!SEL || (J == 2 && A32 && NT == RB_SNT), "second launch behind the 32-bit kernel: J = 2, u32 totals");
+        {   // (1) finalize: totals of this workgroup's slice of curves = sum of the Gsum partial blocks (16-byte loads)
+            const u32 *P = reinterpret_cast<const u32 *>(partial);
+            u64 *redl = reinterpret_cast<u64 *>(Sm);                  // [64 slices][16 quads][4]
+            const int nq = n >> 2;                                    // n % 4 == 0 (host)
+            const int q0 = (int)((i64)blockIdx.x * nq / gridDim.x), q1 = (int)((i64)(blockIdx.x + 1) * nq / gridDim.x);
+            const int qx = t0 & 15, y = t0 >> 4;
+            for (int qb = q0; qb < q1; qb += 16) {
+                u64 a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+                if (qb + qx < q1) {
+                    const u32 *pp = P + 4 * (qb + qx);
+#pragma unroll 4
+                    for (int g = y; g < Gsum; g += 64) {
+                        const uint4 v = *reinterpret_cast<const uint4 *>(pp + (size_t)g * n);
+                        a0 += v.x; a1 += v.y; a2 += v.z; a3 += v.w;
+                    }
+                }
+                u64 *rl = redl + ((size_t)y * 16 + qx) * 4;
+                rl[0] = a0; rl[1] = a1; rl[2] = a2; rl[3] = a3;
+                __syncthreads();
+                if (t0 < 64 && qb + (t0 >> 2) < q1) {
+                    u64 tot = 0;
+#pragma unroll 8
+                    for (int k = 0; k < 64; ++k) tot += redl[((size_t)k * 16 + (t0 >> 2)) * 4 + (t0 & 3)];
+                    atomicAdd(&out_tot[4 * (qb + (t0 >> 2)) + (t0 & 3)], tot);
+                }
+                __syncthreads();
+            }
+        }
+        {   // (1b) the keys rank_bucket32_kernel set aside (equal 32-bit images): their rows are NaN-free and finite, a group
+            //      of equal images is complete in its workgroup's list, so B and A follow from the list and the doubles
+            constexpr int LCAP = 64, LW = 1 + 2 * LCAP;               // R32_LCAP, R32_LIST_WORDS (mbd_rank_bucket32.hip)
+            for (int w = blockIdx.x; w < Gsum; w += gridDim.x) {
+                const u32 *lb = listbuf + (size_t)w * LW;
+                const u32 L = lb[0];
+                if ((u32)t0 < L && L <= (u32)LCAP) {
+                    const u32 key = lb[1 + t0], be = lb[1 + LCAP + t0];
+                    const u32 c = key & 0x3FFFu;
+                    const double *rowp = Y + (row0 + (i64)w + (i64)(key >> 14) * Gsum) * n;
+                    const double xv = rowp[c];
+                    u32 B = be & 0xFFFFu, A = (u32)n - B - (be >> 16);
+                    for (u32 j = 0; j < L; ++j) {
+                        const u32 kj = lb[1 + j];
+                        if (j != (u32)t0 && (kj >> 14) == (key >> 14) && (lb[1 + LCAP + j] & 0xFFFFu) == (be & 0xFFFFu)) {
+                            const double xj = rowp[kj & 0x3FFFu];
+                            B += (xj < xv) ? 1u : 0u;
+                            A += (xj > xv) ? 1u : 0u;
+                        }
+                    }
+                    const u64 v = (u64)n - 1;
+                    atomicAdd(&out_tot[c], (v * (v - 1) - (u64)A * (A - 1) - (u64)B * (B - 1)) >> 1);
+                }
+            }
+        }
+        if (*gate != epoch) return;                                   // (2) nothing was flagged
+        unsigned short *selw = const_cast<unsigned short *>(sel);
+        u32 nsel = 0;
+        for (i64 c0 = 0; c0 < rows; c0 += NT) {
+            const bool f = (c0 + t0 < rows) && rowflag[c0 + t0];
+            const u64 m = __ballot(f);
+            if ((t0 & 63) == 0) wtot[t0 >> 6] = (u32)__popcll(m);
+            __syncthreads();
+            u32 off = nsel, tot = 0;
+            for (int w = 0; w < NW; ++w) {
+                const u32 c = wtot[w];
+                off += (w < (t0 >> 6)) ? c : 0u;
+                tot += c;
+            }
+            if (f) selw[off + (u32)__popcll(m & ((1ull << (t0 & 63)) - 1ull))] = (unsigned short)(c0 + t0);
+            nsel += tot;
+            __syncthreads();
+        }
+        rows = nsel;                                                  // from here on "row r" is the r-th flagged row
+    }
+    auto rowptr = [&](i64 r) -> const double * {
+        if constexpr (SEL) return Y + (row0 + (i64)sel[r]) * n;
+        else return Y + (row0 + r) * n;
+    };
 
     // LDS setup (once, and again behind rb_slow_row): sentinels + dummy range, empty histogram
     auto lds_setup = [&]() {
@@ -194,7 +285,7 @@ __global__ __launch_bounds__(NT, RB_WAVES_PER_EU(E)) void rank_bucket_kernel(con
     // curves of thread t: t, t + NT, ...; slots beyond n read as NaN and are treated like any other NaN
     double k[E];
     auto load_row = [&](i64 r) {
-        const double *rp = Y + (row0 + r) * n + t;
+        const double *rp = rowptr(r) + t;
 #pragma unroll
         for (int e = 0; e < E; ++e) k[e] = (e < E - 1 || t + (E - 1) * NT < n) ? rp[e * NT] : QNAN;
     };
@@ -253,7 +344,7 @@ __global__ __launch_bounds__(NT, RB_WAVES_PER_EU(E)) void rank_bucket_kernel(con
         mark(1);
         double lo, hi;
         {
-            const double2 p = reinterpret_cast<const double2 *>(redp)[lane & 15];
+            const double2 p = reinterpret_cast<const double2 *>(redp)[lane & (NW - 1)];
             lo = rb_readlane_f64(rb_row_allreduce<false>(p.x), 0);
             hi = rb_readlane_f64(rb_row_allreduce<true>(p.y), 0);
             if constexpr (E >= 2 && RB_ROBUST) {
@@ -328,7 +419,7 @@ __global__ __launch_bounds__(NT, RB_WAVES_PER_EU(E)) void rank_bucket_kernel(con
                 if (lane == 63) wtot[wave] = wsum | (wover ? 0x80000000u : 0u) | (wtry ? 0x40000000u : 0u);
                 mark(3);
                 __syncthreads();                                      // barrier 3
-                const u32 wt = wtot[lane & 15];
+                const u32 wt = wtot[lane & (NW - 1)];
                 crowded = __ballot((wt >> 31) != 0) != 0;
                 trypure = RB_TIES && __ballot((wt & 0x40000000u) != 0) != 0;
                 const u32 wscan = rb_row_incl_scan(wt & 0x3FFFFFFFu);
@@ -569,12 +660,14 @@ __global__ __launch_bounds__(NT, RB_WAVES_PER_EU(E)) void rank_bucket_kernel(con
     }
     // ---- this workgroup's partial totals (u32 when the host found that they fit: J = 2, few rows per workgroup) ----
     u64 *P = partial + (size_t)blockIdx.x * (J > 0 ? J - 1 : 0) * n;
-    u32 *P32 = reinterpret_cast<u32 *>(partial) + (size_t)blockIdx.x * n;
+    // SEL: the totals of the flagged rows go to this workgroup's own u32 block (summed by the last workgroups to arrive, below)
+    u32 *P32 = SEL ? fblocks + (size_t)blockIdx.x * n : reinterpret_cast<u32 *>(partial) + (size_t)blockIdx.x * n;
 #pragma unroll
     for (int e = 0; e < E; ++e)
         if ((J > 0) && (e < E - 1 || t + (E - 1) * NT < n)) {
             if constexpr (J == 2) {
-                if (p32) P32[t + e * NT] = (u32)(acc[e][0] >> 1);
+                if constexpr (SEL) P32[t + e * NT] = (u32)(acc[e][0] >> 1);
+                else if (p32) P32[t + e * NT] = (u32)(acc[e][0] >> 1);
                 else P[t + e * NT] = acc[e][0] >> 1;
             } else {
 #pragma unroll
@@ -585,13 +678,14 @@ __global__ __launch_bounds__(NT, RB_WAVES_PER_EU(E)) void rank_bucket_kernel(con
     //      The main loop's accumulators are already in HBM and dead here, so this cold code shares no registers
     //      with the hot loop; each thread adds its own curves' band counts to what it stored above. ----
 #ifndef RB_NO_COLD
+    if constexpr (NT == RB_SNT)
     if (ndefer) {                                                     // block-uniform
         __syncthreads();
         rowidx = 0;
         for (i64 r = blockIdx.x; r < rows; r += gridDim.x, ++rowidx) {
             if (!((defer[rowidx >> 5] >> (rowidx & 31)) & 1u)) continue;
             u32 ab[RB_SE], nnan_s;
-            rb_slow_row(Y + (row0 + r) * n, n, IMG, wtot, ab, &nnan_s);
+            rb_slow_row(rowptr(r), n, IMG, wtot, ab, &nnan_s);
 #pragma unroll 1
             for (int e = 0; e < RB_SE; ++e) {
                 if constexpr (J == 0) {
@@ -600,7 +694,7 @@ __global__ __launch_bounds__(NT, RB_WAVES_PER_EU(E)) void rank_bucket_kernel(con
                 } else if (ab[e] != RB_AB_SPECIAL) {                         // implies t + e * NT < n
                     u64 a7[JMAX - 1] = {0, 0, 0, 0, 0, 0, 0};
                     band_counts_add<(J > 0 ? J : 2)>(ab[e] >> 16, ab[e] & 0xFFFFu, nnan_s, (u64)(n - 1), a7);
-                    if (J == 2 && p32) P32[t + e * NT] += (u32)a7[0];
+                    if (SEL || (J == 2 && p32)) P32[t + e * NT] += (u32)a7[0];
                     else {
 #pragma unroll
                         for (int j = 0; j < J - 1; ++j) P[(size_t)j * n + t + e * NT] += a7[j];
@@ -610,6 +704,52 @@ __global__ __launch_bounds__(NT, RB_WAVES_PER_EU(E)) void rank_bucket_kernel(con
         }
     }
 #endif
+    if constexpr (SEL) {
+        // ---- the flagged rows' totals: G blocks of u32 -> out_tot.  Adding them with atomics from every workgroup costs
+        //      G same-address atomics per curve (20 us at G = 256); instead each workgroup publishes its block, takes a
+        //      ticket, and the LAST workgroups to arrive each sum one slice of the curves over all blocks.  They wait only
+        //      for workgroups that are already running (a ticket is taken at the end of the work, and all but K - 1 others
+        //      have left by then), so the wait ends whatever share of the CUs this launch gets. ----
+        const int G = (int)gridDim.x, K = G < 16 ? G : 16;
+        __syncthreads();                                              // this workgroup's block is complete (stores acknowledged) ...
+        if (t0 == 0) {
+            __threadfence();                                          // ... and written back for the device (ONE fence per workgroup)
+            const u32 ticket = atomicAdd(done, 1u);                   // *done was zeroed by rank_bucket32_kernel
+            wtot[0] = ticket;
+            if (ticket >= (u32)(G - K))
+                while (__hip_atomic_load(done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (u32)G) __builtin_amdgcn_s_sleep(8);
+            __threadfence();                                          // acquire: the other workgroups' blocks
+        }
+        __syncthreads();
+        const u32 ticket = wtot[0];
+        if (ticket < (u32)(G - K)) return;
+        const int my = (int)ticket - (G - K);
+        u64 *redl = reinterpret_cast<u64 *>(Sm);                      // [16 slices][64 quads][4]
+        const int nq = n >> 2;
+        const int q0 = (int)((i64)my * nq / K), q1 = (int)((i64)(my + 1) * nq / K);
+        const int qx = t0 & 63, y = t0 >> 6;
+        for (int qb = q0; qb < q1; qb += 64) {
+            u64 a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+            if (qb + qx < q1) {
+                const u32 *pp = fblocks + 4 * (qb + qx);
+#pragma unroll 8
+                for (int g = y; g < G; g += 16) {
+                    const uint4 v = *reinterpret_cast<const uint4 *>(pp + (size_t)g * n);
+                    a0 += v.x; a1 += v.y; a2 += v.z; a3 += v.w;
+                }
+            }
+            u64 *rl = redl + ((size_t)y * 64 + qx) * 4;
+            rl[0] = a0; rl[1] = a1; rl[2] = a2; rl[3] = a3;
+            __syncthreads();
+            if (t0 < 256 && qb + (t0 >> 2) < q1) {
+                u64 tot = 0;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) tot += redl[((size_t)k * 64 + (t0 >> 2)) * 4 + (t0 & 3)];
+                atomicAdd(&out_tot[4 * (qb + (t0 >> 2)) + (t0 & 3)], tot);
+            }
+            __syncthreads();
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -684,7 +824,7 @@ __global__ __launch_bounds__(NT) void rank_external_kernel(const double *__restr
         __syncthreads();                                              // barrier 1
         double lo, hi;
         {
-            const double2 p = reinterpret_cast<const double2 *>(redp)[lane & 15];
+            const double2 p = reinterpret_cast<const double2 *>(redp)[lane & (NW - 1)];
             lo = rb_readlane_f64(rb_row_allreduce<false>(p.x), 0);
             hi = rb_readlane_f64(rb_row_allreduce<true>(p.y), 0);
             if constexpr (E >= 2 && RB_ROBUST) {                      // outlier-robust range, as in rank_bucket_kernel
@@ -958,7 +1098,24 @@ static int launch_bucket_cfg(const double *Y, i64 n, i64 row0, i64 rows, u64 *pa
     const size_t lds = C::lds_bytes((int)n);
     if (lds > 163840) return fail(SD_ERR_UNSUPPORTED, "bucket kernel: %zu bytes of LDS for n=%lld", lds, (long long)n);
     SD_HIP(hipFuncSetAttribute((const void *)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kf, dim3(G), dim3(NT), lds, s, Y, n, row0, rows, partial, p32, nnan_img);
+    hipLaunchKernelGGL(kf, dim3(G), dim3(NT), lds, s, Y, n, row0, rows, partial, p32, nnan_img, (const unsigned char *)nullptr,
+                       (const u32 *)nullptr, 0u, (u64 *)nullptr, 0, (const u32 *)nullptr, (u32 *)nullptr, (u32 *)nullptr);
+    SD_HIP(hipGetLastError());
+    return SD_OK;
+}
+
+// second launch behind rank_bucket32_kernel: the rows it flagged, totals added to its partial blocks
+template <int E, int LNB>
+static int launch_bucket_sel_cfg(const double *Y, i64 n, i64 row0, i64 rows, u64 *partial, int G, const unsigned char *rowflag,
+                                 const u32 *gate, u32 epoch, u64 *out, int Gsum, const u32 *listbuf, u32 *fblocks, u32 *done,
+                                 hipStream_t s) {
+    using C = RBCfg<1024, E, LNB, 3>;
+    auto kf = rank_bucket_kernel<1024, E, LNB, 2, RB_CAP, 3, 0, true, true>;
+    const size_t lds = C::lds_bytes((int)n) + 8192;
+    if (lds > 163840) return fail(SD_ERR_UNSUPPORTED, "bucket kernel: %zu bytes of LDS for n=%lld", lds, (long long)n);
+    SD_HIP(hipFuncSetAttribute((const void *)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kf, dim3(G), dim3(1024), lds, s, Y, n, row0, rows, partial, 2, (u32 *)nullptr, rowflag, gate, epoch, out, Gsum, listbuf,
+                       fblocks, done);
     SD_HIP(hipGetLastError());
     return SD_OK;
 }
@@ -971,6 +1128,11 @@ static int launch_bucket_j(const double *Y, i64 n, i64 row0, i64 rows, u64 *part
     // J = 3 stays at 16384: the wider prefix arrays push it further into scratch); first member pass: 3 x 16 bytes
 #define RB_ARGS Y, n, row0, rows, partial, p32, G, s
     const int E = (int)((n + 1023) / 1024);
+#ifdef RB_HALF                                            // timing experiment: two 512-thread workgroups per CU (no cold path)
+    if constexpr (J == 2) {
+        if (E == 5) return launch_bucket_cfg<512, 10, 14, 2, 3>(RB_ARGS);
+    }
+#endif
 #ifdef SD_TUNING
     if (E == 10 && J == 2) {                              // tuning experiments on the config-2 shape
         const char *eu = getenv("SD_RB_U2"), *el = getenv("SD_RB_LNB");
@@ -1020,12 +1182,53 @@ int launch_rank_bucket_image(const double *Y, i64 n, i64 row0, i64 rows, u32 *AB
     return fail(SD_ERR_UNSUPPORTED, "bucket kernel covers n <= 16384");
 }
 
+// mbd_rank_bucket32.hip: 32-bit key images, two workgroups per CU
+bool rank_bucket32_supported(i64 n, i64 rows, int cus);
+size_t rank_bucket32_extra_bytes(i64 rows);
+int launch_rank_bucket32(const double *Y, i64 n, i64 row0, i64 rows, u32 *partial, unsigned char *rowflag, u32 *gate, u32 epoch,
+                         u64 *out_zero, u32 *listbuf, int G, hipStream_t s);
+size_t rank_bucket32_list_bytes(int G);
+u32 rank_bucket32_epoch();
+
+// J = 2, 4096 < n <= 11264, every curve a target: rank_bucket32_kernel (two workgroups per CU; zeroes out when `first`) + the
+// fp64 kernel's SEL form (sums the partial blocks into out; ranks the rows the first kernel flagged).  Two launches.  The
+// flags and the gate word sit behind the 2 * cus u32 partial blocks, inside the space sized for u64 blocks.
+bool rank_bucket_two_level_supported(i64 n, i64 rows) {
+    return (n % 4) == 0 && rank_bucket32_supported(n, rows, rb_cus()) &&
+           (size_t)rows + 512 + rank_bucket32_list_bytes(2 * rb_cus()) + (size_t)rb_cus() * n * 4 <= (size_t)2 * rb_cus() * n * 4;
+}
+
+int launch_rank_bucket_two_level(const double *Y, i64 n, i64 row0, i64 rows, u64 *partial, u64 *out, int first, hipStream_t s) {
+    const int cus = rb_cus();
+    const int G = (int)(rows < 2 * cus ? rows : 2 * cus);
+    u32 *P32 = reinterpret_cast<u32 *>(partial);
+    unsigned char *rowflag = reinterpret_cast<unsigned char *>(P32 + (size_t)2 * cus * n);
+    u32 *gate = reinterpret_cast<u32 *>(rowflag + align_up((size_t)rows, 64));
+    u32 *listbuf = gate + 16;                                         // a list of set-aside keys per workgroup of the first launch
+    // the second launch's own blocks (totals of the flagged rows), 16-byte aligned, behind the lists; gate[2]: arrival counter
+    u32 *fblocks = reinterpret_cast<u32 *>(align_up((size_t)(listbuf) + rank_bucket32_list_bytes(G), 256));
+    const u32 epoch = rank_bucket32_epoch();
+    int rc = launch_rank_bucket32(Y, n, row0, rows, P32, rowflag, gate, epoch, first ? out : nullptr, listbuf, G, s);
+    if (rc) return rc;
+    const int G2 = G < cus ? G : cus;
+#define RB_SEL(E_) case E_: return launch_bucket_sel_cfg<E_, 14>(Y, n, row0, rows, partial, G2, rowflag, gate, epoch, out, G, listbuf, fblocks, gate + 2, s);
+    switch ((int)((n + 1023) / 1024)) {
+        RB_SEL(5) RB_SEL(6) RB_SEL(7) RB_SEL(8) RB_SEL(9) RB_SEL(11)
+        case 10: return launch_bucket_sel_cfg<10, 15>(Y, n, row0, rows, partial, G2, rowflag, gate, epoch, out, G, listbuf, fblocks, gate + 2, s);
+    }
+#undef RB_SEL
+    return fail(SD_ERR_UNSUPPORTED, "two-level bucket path covers 4096 < n <= 11264");
+}
+
 // rows [row0, row0 + rows): partial totals of every curve per workgroup; returns the grid used (number of partial
 // blocks) in *G_out
 int launch_rank_bucket(const double *Y, i64 n, i64 row0, i64 rows, int J, u64 *partial, int *p32_out, int *G_out,
                        hipStream_t s) {
     // one workgroup per CU; two where the kernel is built for 64 VGPRs (few keys per thread)
-    const int cus = rb_cus() * (((n + 1023) / 1024) <= RB_SMALL_E ? 2 : 1);
+    int cus = rb_cus() * (((n + 1023) / 1024) <= RB_SMALL_E ? 2 : 1);
+#ifdef RB_HALF
+    if ((n + 1023) / 1024 == 5 && J == 2) cus = 2 * rb_cus();
+#endif
     const int G = (int)(rows < cus ? rows : cus);
     *G_out = G;
     if (rows > (i64)G * 2048) return fail(SD_ERR_INVALID, "bucket kernel: more than 2048 rows per workgroup in one launch");
@@ -1124,7 +1327,7 @@ __global__ __launch_bounds__(NT) void rank_medium_image_kernel(const double *__r
             __syncthreads();                                          // barrier 1
             double lo, hi;
             {
-                const double2 p = reinterpret_cast<const double2 *>(redp)[lane & 15];
+                const double2 p = reinterpret_cast<const double2 *>(redp)[lane & (NW - 1)];
                 lo = rb_readlane_f64(rb_row_allreduce<false>(p.x), 0);
                 hi = rb_readlane_f64(rb_row_allreduce<true>(p.y), 0);
                 if constexpr (RB_ROBUST) {                            // outlier-robust range, as in rank_bucket_kernel
