@@ -25,6 +25,8 @@ if os.environ.get("SD_OUTLIER_RANDOM"):          # ... at random positions (ever
 if os.environ.get("SD_CAUCHY"):                  # heavy tails at every timepoint
     X = np.random.default_rng(5).standard_cauchy(size=(T, n))
 Xd = engine.to_device_matrix(X)
+ROT = int(os.environ.get("SD_ROTATE", "1"))      # > 1: that many distinct matrices in rotation (every call streams from HBM)
+Xs = [Xd] + [engine.to_device_matrix(X + float(k)) for k in range(1, ROT)]
 if os.environ.get("SD_RANK_IMPL"):
     print("SD_RANK_IMPL =", os.environ["SD_RANK_IMPL"])
 for lvl in os.environ.get("SD_LEVELS", "0").split(","):
@@ -37,8 +39,8 @@ for lvl in os.environ.get("SD_LEVELS", "0").split(","):
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(reps):
-        engine.mbd_counts(Xd, None, 2, algo="rank", return_tensor=True)
+    for i in range(reps):
+        engine.mbd_counts(Xs[i % ROT], None, 2, algo="rank", return_tensor=True)
     e1.record()
     torch.cuda.synchronize()
     print(f"n={n} T={T} dbg={lvl}: {e0.elapsed_time(e1) / reps:.4f} ms per call", flush=True)
