@@ -137,7 +137,229 @@ __global__ __launch_bounds__(R32_NT, 4) void rank_bucket32_kernel(const double *
         // the second launch (gate[1] = epoch << 8 | count; block-uniform scalar load, a few rows stale at worst)
         if (rowidx && t == 0) misc[3] = __hip_atomic_load(gate + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ONE load per workgroup
         __builtin_amdgcn_s_setprio(R32_PRIO_LDS);                     // latency-bound phases go first, the compares of the member
-        load_row(r);                                                  // pass (the other workgroup's, half a row away) fill in
+        load_row(r);                                                  // pass (the other workgroup's, half a row away) fill in                                                  // the other workgroup of this CU works under this latency
+        row_range(par);
+        R32_MARK(1)
+        double *redp = red + par * 2 * NW;
+        par ^= 1;
+        __syncthreads();                                              // barrier 1 (histogram is zero, S is free)
+        R32_MARK(2)
+        if (rowidx) {                                                 // block-uniform: everybody reads the word thread 0 fetched
+            const u32 w = misc[3];
+            if ((w >> 8) == (epoch & 0xFFFFFFu) && (w & 0xFFu) >= 8u) { stop = true; break; }
+        }
+        double lo, hi;
+        {
+            const double2 p = reinterpret_cast<const double2 *>(redp)[lane & (NW - 1)];
+            lo = rb_readlane_f64(rb_row_allreduce<false>(p.x), 0);
+            hi = rb_readlane_f64(rb_row_allreduce<true>(p.y), 0);
+            // outlier-robust range, as in rank_bucket_kernel: the innermost of the waves' minima and maxima bracket the bulk
+            const float l2 = rb_row_allreduce_f32<true>((float)p.x), h2 = rb_row_allreduce_f32<false>((float)p.y);
+            const double lo2 = (double)__int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(l2)));
+            const double hi2 = (double)__int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(h2)));
+            const double sp = hi2 - lo2;
+            if (sp > 0.0 && sp < INF && (hi - lo) > 8.0 * sp) {       // block-uniform
+                const double nlo = lo2 - 1.5 * sp, nhi = hi2 + 1.5 * sp;
+                lo = nlo > lo ? nlo : lo;
+                hi = nhi < hi ? nhi : hi;
+            }
+        }
+        const double scale = (hi > lo) ? R32_TOP / (hi - lo) : 0.0;
+        // hi < lo: no value at this timepoint (every curve NaN), nothing is contained.  Else a row with an infinity, an
+        // overflowing range or all values equal (scale 0: one bucket) is handed over.
+        const bool go = (hi > lo) && (scale < INF) && (lo > -INF) && (hi < INF);
+        bool bad = !go && (hi >= lo);
+        u32 sl[(E + 3) / 4];
+        if (go) {
+            // ---- (1) image, bucket, slot: trunc(min(fl(fl(x - lo) * scale), TOP)), negative -> 0, is non-decreasing in x ----
+#pragma unroll
+            for (int e = 0; e < (E + 3) / 4; ++e) sl[e] = 0;
+            // batches of 8 atomics in flight; their return values (the slots) are packed 4 to a register per batch
+#pragma unroll
+            for (int e0 = 0; e0 < E; e0 += 8) {
+                u32 old[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int e = e0 + i;
+                    if (e < E) {
+                        const double xv = x[e];
+                        double u = (xv - lo) * scale;
+                        u = u < R32_TOP ? u : R32_TOP;                // NaN -> TOP (bucket overridden below)
+                        u32 qi;
+                        asm("v_cvt_u32_f64 %0, %1" : "=v"(qi) : "v"(u));   // saturating: below the range -> 0
+                        kb[e] = qi;
+                        const u32 b = (xv == xv) ? (qi >> SH) : (u32)(NB + 2);
+                        old[i] = atomicAdd(&H[b >> 1], 1u << ((b & 1u) * 16u));
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int e = e0 + i;
+                    if (e < E)   // a NaN key's slot is read from the wrong half: its row is not taken anyway
+                        sl[e >> 2] |= ((old[i] >> (((kb[e] >> SH) & 1u) * 16u)) & 0xFFu) << (8 * (e & 3));
+                }
+                asm volatile("" : "+v"(sl[e0 >> 2]));                 // packed HERE: not (old, shift) pairs kept for the scatter
+                if (e0 + 4 < E) asm volatile("" : "+v"(sl[(e0 >> 2) + 1]));
+            }
+            R32_MARK(3)
+            __syncthreads();                                          // barrier 2
+            R32_MARK(4)
+            // ---- (2) exclusive prefix sum over the counters (conflict-free 16-byte accesses: lane <-> quad) ----
+            uint4 *Hq = reinterpret_cast<uint4 *>(H) + wave * (64 * QW);
+            uint4 hq[QW];
+            u32 runq[QW], inclq[QW], offq[QW], ov = 0, wsum = 0;
+#pragma unroll
+            for (int i = 0; i < QW; ++i) {
+                hq[i] = Hq[i * 64 + lane];
+                const u32 s4 = hq[i].x + hq[i].y + hq[i].z + hq[i].w;
+                ov |= hq[i].x | hq[i].y | hq[i].z | hq[i].w;          // bit k of a half set <=> some counter has it
+                runq[i] = (s4 & 0xFFFFu) + (s4 >> 16);
+                inclq[i] = rb_wave_incl_scan(runq[i]);
+                offq[i] = wsum;
+                wsum += rb_readlane(inclq[i], 63);
+            }
+            const bool wover = __ballot((ov & 0xFFC0FFC0u) != 0) != 0;   // some bucket holds 64 keys or more
+            const bool wtry = __ballot((ov & 0xFFF0FFF0u) != 0) != 0;    // ... 16 or more: ties rather than density?
+            if (lane == 63) wtot[wave] = wsum | (wover ? 0x80000000u : 0u) | (wtry ? 0x40000000u : 0u);
+            R32_MARK(5)
+            __syncthreads();                                          // barrier 3
+            const u32 wt = wtot[lane & (NW - 1)];
+            const bool crowded = __ballot((wt >> 31) != 0) != 0;
+            const bool trypure = __ballot((wt & 0x40000000u) != 0) != 0;
+            const u32 wscan = rb_row_incl_scan(wt & 0x3FFFFFFFu);
+            const u32 woff = wave ? rb_readlane(wscan, wave - 1) : 0u;
+#pragma unroll
+            for (int i = 0; i < QW; ++i) {
+                u32 base = woff + offq[i] + inclq[i] - runq[i];
+                uint4 o;
+                o.x = base | ((base + (hq[i].x & 0xFFFFu)) << 16);
+                base += (hq[i].x & 0xFFFFu) + (hq[i].x >> 16);
+                o.y = base | ((base + (hq[i].y & 0xFFFFu)) << 16);
+                base += (hq[i].y & 0xFFFFu) + (hq[i].y >> 16);
+                o.z = base | ((base + (hq[i].z & 0xFFFFu)) << 16);
+                base += (hq[i].z & 0xFFFFu) + (hq[i].z >> 16);
+                o.w = base | ((base + (hq[i].w & 0xFFFFu)) << 16);
+                base += (hq[i].w & 0xFFFFu) + (hq[i].w >> 16);
+                Hq[i * 64 + lane] = o;
+                if (i == QW - 1 && t == NT - 1) H[NB / 2] = base;     // base past the last bucket = number of non-NaN keys
+            }
+            __syncthreads();                                          // barrier 4
+            R32_MARK(6)
+            const u32 nv = H[NB / 2];
+            // block-uniform.  A crowded row (a bucket of 64 keys or more) is scattered too: its slots wrap at 256 but stay inside
+            // their buckets, which is all the closed form below asks of S; its member pass is never run.
+            bool take = nv == (u32)n;
+            u32 bc[E];                                                // base | count << 14
+            if (take) {
+                // ---- (3) scatter into bucket order ----
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    const u32 b = kb[e] >> SH, slot = (sl[e >> 2] >> (8 * (e & 3))) & 0xFFu;
+                    // two 2-byte reads, kept apart: merged into one 4-byte read they sit on an odd halfword for every
+                    // odd b, and the LDS replays such a read for 64 cycles (SQ_LDS_UNALIGNED_STALL)
+                    u32 b1 = b + 1u;
+                    asm("" : "+v"(b1));                               // adjacency hidden from the load vectoriser
+                    const u32 base = H16[b], end = H16[b1];
+                    const bool isk = e < E - 2 || t + e * NT < n;
+                    S[isk ? base + slot : (u32)DUMMY] = kb[e];
+                    bc[e] = base | ((end - base) << 14);
+                }
+            }
+            R32_MARK(7)
+            __syncthreads();                                          // barrier 5
+            R32_MARK(8)
+            bool pure = false;                                        // block-uniform: the row is ranked in closed form
+            if (take && (trypure || crowded)) {
+                // A bucket of 16 keys or more is tie-heavy (quantised) data more often than a dense cluster.  When a key
+                // there shares its image with the first two keys of its bucket, the row is tried in closed form: if every
+                // bucket of the row holds ONE value, the ranks are B = base, A = n - base - count and there is no member
+                // pass at all.  One value per bucket is PROVEN on the doubles: equal images (the first key's, in S), then
+                // equal high and low words -- every key of a bucket writes its words to the bucket's first two slots (one
+                // key's land) and all compare with what landed.  A row that fails any of it is handed over.
+                const u32 tag = rowidx + 1u;                          // misc words tagged by the row: nothing to reset
+                bool vote = false, same = true;
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    const u32 base = bc[e] & 0x3FFFu, cnt = bc[e] >> 14;
+                    if (e < E - 2 || t + e * NT < n) {
+                        const u32 first = S[base];
+                        same = same && (first == kb[e]);
+                        if (cnt >= 16u) vote = vote || (first == kb[e] && S[base + 1] == kb[e]);
+                    }
+                }
+                if (vote) misc[2] = tag;
+                if (!same) misc[4] = tag;
+                __syncthreads();
+                if (misc[2] == tag || crowded) {                      // tie-heavy: closed form or hand-over, never the member pass
+                    take = false;
+                    bool ok = misc[2] == tag && misc[4] != tag;       // block-uniform
+                    if (ok) {
+                        // the doubles again (L2; their registers went to the images); -0 counts as +0.  A bucket of two keys
+                        // or more takes the high word in its first slot and the low word in its second.  Four keys at a time
+                        // (loaded again for the comparison): this cold path must not cost the row loop its registers.
+                        const double *rp = Y + (row0 + r) * n + t;
+#pragma unroll
+                        for (int pass = 0; pass < 2; ++pass) {
+                            bool eq = true;
+#pragma unroll
+                            for (int e0 = 0; e0 < E; e0 += 4) {
+                                int eo = e0 * NT;                     // opaque: one address computation per group, none hoisted
+                                asm volatile("" : "+v"(eo));
+                                const double *rq = rp + eo;
+                                u64 w[4];
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) {
+                                    const bool isk = e0 + i < E && (e0 + i < E - 2 || t + (e0 + i) * NT < n);
+                                    w[i] = (u64)__double_as_longlong((isk ? rq[i * NT] : 0.0) + 0.0);
+                                }
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) {
+                                    if (e0 + i < E && (e0 + i < E - 2 || t + (e0 + i) * NT < n) && (bc[e0 + i] >> 14) >= 2u) {
+                                        u32 *sp = S + (bc[e0 + i] & 0x3FFFu);
+                                        if (pass == 0) { sp[0] = (u32)(w[i] >> 32); sp[1] = (u32)w[i]; }
+                                        else eq = eq && sp[0] == (u32)(w[i] >> 32) && sp[1] == (u32)w[i];
+                                    }
+                                }
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
+                            if (pass == 1 && !eq) misc[4] = tag;
+                            __syncthreads();
+                        }
+                        ok = misc[4] != tag;
+                    }
+                    if (ok) {
+                        pure = true;
+#pragma unroll
+                        for (int e = 0; e < E; ++e) {
+                            const u32 B = bc[e] & 0x3FFFu, A = (u32)n - B - (bc[e] >> 14);
+                            acc[e] += (e < E - 2 || t + e * NT < n) ? (nm1 * (nm1 - 1u) - A * (A - 1u) - B * (B - 1u)) >> 1 : 0u;
+                        }
+                    }
+                }
+            }
+            __builtin_amdgcn_s_setprio(R32_PRIO_VALU);
+            {                                                         // the histogram is dead until the next row's atomics
+                uint4 *Hz = reinterpret_cast<uint4 *>(H) + wave * (64 * QW);
+#pragma unroll
+                for (int i = 0; i < QW; ++i) Hz[i * 64 + lane] = make_uint4(0, 0, 0, 0);
+                if (t < 2) H[NB / 2 + t] = 0;
+            }
+            if (take) {
+                // ---- (4) rank inside the bucket: two quads from the 16-byte boundary at or below the bucket's base; the
+                //      keys in front of the base belong to earlier buckets (smaller images) and are taken off again, keys
+                //      past the bucket's end have larger images, sentinels follow the last key.  Only `<` is counted:
+                //      equal images show in the sum of the row's ranks (fold above) ----
+                const uint4 *S4 = reinterpret_cast<const uint4 *>(S);
+                uint4 y0, y1;
+                auto window = [&](int e) {
+                    const u32 base = bc[e] & 0x3FFFu, cnt = bc[e] >> 14;
+                    const uint4 *p = S4 + (base >> 2);
+                    y0 = p[0];
+#ifdef R32_NOREDIRECT
+                    y1 = p[1];
+#else
+                    y1 = *((cnt + (base & 3u) > 4u) ? p + 1 : SENT);
+#endif
                 };
                 u32 sB = 0;
                 window(0);
