@@ -241,6 +241,40 @@ def test_bench_contract_and_committed_evidence():
     assert abs(line["roofline"]["frac"] - line["roofline"]["achieved"] / line["roofline"]["peak"]) < 1e-9
 
 
+def test_committed_profiles_are_of_the_shipped_kernels():
+    """The newest committed kernel statistics of the headline workload must not predate the last commit that touched the
+    kernels it measures: a stale profile is evidence of another build."""
+    import subprocess
+
+    def last_commit_time(paths):
+        out = subprocess.run(["git", "-C", ROOT, "log", "-1", "--format=%ct", "--"] + paths, capture_output=True, text=True)
+        return int(out.stdout.strip()) if out.returncode == 0 and out.stdout.strip() else None
+
+    if last_commit_time(["bench.py"]) is None:
+        pytest.skip("no git history here")
+    stats = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("bench_kernel_stats.csv"))
+    assert stats
+    newest = os.path.join("profiles", stats[-1])
+    with open(os.path.join(ROOT, newest)) as f:
+        names = f.read()
+    assert "rank_bucket32_kernel" in names, "the committed headline profile is not of the two-launch path"
+    t_prof = last_commit_time([newest])
+    t_kern = last_commit_time(["statdepth_amd/csrc/mbd_rank_bucket32.hip", "statdepth_amd/csrc/mbd_rank_bucket.hip",
+                               "statdepth_amd/csrc/rank_bucket.h"])
+    if t_prof is None:
+        pytest.skip("profile not committed yet")
+    assert t_prof >= t_kern, f"{newest} predates the last change of the kernels it measures: run tools/collect_profiles.py"
+    # bench.py quotes traffic and kernel time from the newest files that hold the kernels of the step
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_module2", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    traffic, source = bench.pmc_traffic(["rank_bucket32_kernel", "rank_bucket_kernel"], 10000, 1000, 2)
+    assert source and 0.5 * 160.08e6 < traffic < 1.5 * 160.08e6
+    kus, ksrc = bench.profiled_kernel_us("rank_bucket32_kernel", 10000, 1000, 2)
+    assert ksrc == newest and 20.0 < kus < 80.0
+
+
 def test_bench_self_launch_plan():
     """`python bench.py --gpus N` (N > 1) without a launcher starts its own ranks from a parent that never touches the GPU;
     under a launcher (WORLD_SIZE set) or at N = 1 the process is a rank itself.  Dry run only: no rank is started here."""
