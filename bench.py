@@ -547,7 +547,7 @@ def main():
         used = "rank" if (args.algo == "rank" or (args.algo == "auto" and J <= 3)) else "pairwise"
         if used == "pairwise":
             kerns = ["mbd_pairwise_kernel"]
-        elif 4096 < n <= 11264 and J == 2 and n % 4 == 0 and n_loc == n and 256 <= T <= 4096:
+        elif 3072 < n <= 11264 and J == 2 and n_loc == n and 256 <= T <= 4096:
             # two launches: 32-bit key images, two workgroups per CU; then rank_bucket_kernel's SEL form (finalize + flagged rows)
             kerns = ["rank_bucket32_kernel", "rank_bucket_kernel"]
         elif n <= 16384:
@@ -558,7 +558,9 @@ def main():
         achieved = bytes_alg / (dev_ms * 1e-3)
         traffic, source = pmc_traffic(kerns, n, T, J) if N == 1 else (None, None)
         kus, ksrc = profiled_kernel_us(kerns[0], n, T, J) if N == 1 else (None, None)
-        mode = args.mode if args.mode != "auto" else ("time" if used == "rank" else "targets")
+        from statdepth_amd.distributed import mode_cost_model
+        model = mode_cost_model(T, n_loc, N, J, args.algo)
+        mode = args.mode if args.mode != "auto" else model["choice"]
         line = {
             "metric": "curve-pairs/sec (MBD)", "value": value, "unit": "curve-pairs/s",
             "n_gpus": N, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
@@ -572,6 +574,9 @@ def main():
                                        (f"targets sharded x{N}, RCCL all-gather of curve blocks" if mode == "targets" else
                                         f"curves owned x{N}, timepoints sharded for the ranking: RCCL all-to-all + reduce-scatter"))},
             "pair_timepoints_per_s": value * T,
+            "mode": {"used": mode, "cost_model_seconds": {"time": model["time"], "targets": model["targets"]},
+                     "note": "statdepth_amd.distributed.mode_cost_model: exchange over one xGMI link per peer + the measured "
+                             "single-GPU ranking rates; mode='auto' takes the cheaper decomposition"},
             "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK, "traffic": traffic, "traffic_source": source,
                          "hbm_rate": (traffic / (dev_ms * 1e-3) / 1e9) if traffic else None,

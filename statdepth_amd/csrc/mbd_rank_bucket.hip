@@ -195,7 +195,7 @@ __global__ __launch_bounds__(NT, (NT == 512 ? 4 : RB_WAVES_PER_EU(E))) void rank
         {   // (1) finalize: totals of this workgroup's slice of curves = sum of the Gsum partial blocks (16-byte loads)
             const u32 *P = reinterpret_cast<const u32 *>(partial);
             u64 *redl = reinterpret_cast<u64 *>(Sm);                  // [64 slices][16 quads][4]
-            const int nq = n >> 2;                                    // n % 4 == 0 (host)
+            const int nst = (n + 3) & ~3, nq = nst >> 2;              // the blocks lie nst words apart: 16-byte aligned whatever n
             const int q0 = (int)((i64)blockIdx.x * nq / gridDim.x), q1 = (int)((i64)(blockIdx.x + 1) * nq / gridDim.x);
             const int qx = t0 & 15, y = t0 >> 4;
             for (int qb = q0; qb < q1; qb += 16) {
@@ -204,14 +204,14 @@ __global__ __launch_bounds__(NT, (NT == 512 ? 4 : RB_WAVES_PER_EU(E))) void rank
                     const u32 *pp = P + 4 * (qb + qx);
 #pragma unroll 4
                     for (int g = y; g < Gsum; g += 64) {
-                        const uint4 v = *reinterpret_cast<const uint4 *>(pp + (size_t)g * n);
+                        const uint4 v = *reinterpret_cast<const uint4 *>(pp + (size_t)g * nst);
                         a0 += v.x; a1 += v.y; a2 += v.z; a3 += v.w;
                     }
                 }
                 u64 *rl = redl + ((size_t)y * 16 + qx) * 4;
                 rl[0] = a0; rl[1] = a1; rl[2] = a2; rl[3] = a3;
                 __syncthreads();
-                if (t0 < 64 && qb + (t0 >> 2) < q1) {
+                if (t0 < 64 && qb + (t0 >> 2) < q1 && 4 * (qb + (t0 >> 2)) + (t0 & 3) < n) {
                     u64 tot = 0;
 #pragma unroll 8
                     for (int k = 0; k < 64; ++k) tot += redl[((size_t)k * 16 + (t0 >> 2)) * 4 + (t0 & 3)];
@@ -661,7 +661,7 @@ __global__ __launch_bounds__(NT, (NT == 512 ? 4 : RB_WAVES_PER_EU(E))) void rank
     // ---- this workgroup's partial totals (u32 when the host found that they fit: J = 2, few rows per workgroup) ----
     u64 *P = partial + (size_t)blockIdx.x * (J > 0 ? J - 1 : 0) * n;
     // SEL: the totals of the flagged rows go to this workgroup's own u32 block (summed by the last workgroups to arrive, below)
-    u32 *P32 = SEL ? fblocks + (size_t)blockIdx.x * n : reinterpret_cast<u32 *>(partial) + (size_t)blockIdx.x * n;
+    u32 *P32 = SEL ? fblocks + (size_t)blockIdx.x * ((n + 3) & ~3) : reinterpret_cast<u32 *>(partial) + (size_t)blockIdx.x * n;
 #pragma unroll
     for (int e = 0; e < E; ++e)
         if ((J > 0) && (e < E - 1 || t + (E - 1) * NT < n)) {
@@ -725,7 +725,7 @@ __global__ __launch_bounds__(NT, (NT == 512 ? 4 : RB_WAVES_PER_EU(E))) void rank
         if (ticket < (u32)(G - K)) return;
         const int my = (int)ticket - (G - K);
         u64 *redl = reinterpret_cast<u64 *>(Sm);                      // [16 slices][64 quads][4]
-        const int nq = n >> 2;
+        const int nst = (n + 3) & ~3, nq = nst >> 2;
         const int q0 = (int)((i64)my * nq / K), q1 = (int)((i64)(my + 1) * nq / K);
         const int qx = t0 & 63, y = t0 >> 6;
         for (int qb = q0; qb < q1; qb += 64) {
@@ -734,14 +734,14 @@ __global__ __launch_bounds__(NT, (NT == 512 ? 4 : RB_WAVES_PER_EU(E))) void rank
                 const u32 *pp = fblocks + 4 * (qb + qx);
 #pragma unroll 8
                 for (int g = y; g < G; g += 16) {
-                    const uint4 v = *reinterpret_cast<const uint4 *>(pp + (size_t)g * n);
+                    const uint4 v = *reinterpret_cast<const uint4 *>(pp + (size_t)g * nst);
                     a0 += v.x; a1 += v.y; a2 += v.z; a3 += v.w;
                 }
             }
             u64 *rl = redl + ((size_t)y * 64 + qx) * 4;
             rl[0] = a0; rl[1] = a1; rl[2] = a2; rl[3] = a3;
             __syncthreads();
-            if (t0 < 256 && qb + (t0 >> 2) < q1) {
+            if (t0 < 256 && qb + (t0 >> 2) < q1 && 4 * (qb + (t0 >> 2)) + (t0 & 3) < n) {
                 u64 tot = 0;
 #pragma unroll
                 for (int k = 0; k < 16; ++k) tot += redl[((size_t)k * 64 + (t0 >> 2)) * 4 + (t0 & 3)];
@@ -1194,15 +1194,17 @@ u32 rank_bucket32_epoch();
 // fp64 kernel's SEL form (sums the partial blocks into out; ranks the rows the first kernel flagged).  Two launches.  The
 // flags and the gate word sit behind the 2 * cus u32 partial blocks, inside the space sized for u64 blocks.
 bool rank_bucket_two_level_supported(i64 n, i64 rows) {
-    return (n % 4) == 0 && rank_bucket32_supported(n, rows, rb_cus()) &&
-           (size_t)rows + 512 + rank_bucket32_list_bytes(2 * rb_cus()) + (size_t)rb_cus() * n * 4 <= (size_t)2 * rb_cus() * n * 4;
+    const size_t nst = (size_t)((n + 3) & ~3);
+    return rank_bucket32_supported(n, rows, rb_cus()) &&
+           (size_t)2 * rb_cus() * nst * 4 + (size_t)rows + 768 + rank_bucket32_list_bytes(2 * rb_cus()) + (size_t)rb_cus() * nst * 4 <=
+               (size_t)2 * rb_cus() * n * 8;
 }
 
 int launch_rank_bucket_two_level(const double *Y, i64 n, i64 row0, i64 rows, u64 *partial, u64 *out, int first, hipStream_t s) {
     const int cus = rb_cus();
     const int G = (int)(rows < 2 * cus ? rows : 2 * cus);
     u32 *P32 = reinterpret_cast<u32 *>(partial);
-    unsigned char *rowflag = reinterpret_cast<unsigned char *>(P32 + (size_t)2 * cus * n);
+    unsigned char *rowflag = reinterpret_cast<unsigned char *>(P32 + (size_t)2 * cus * ((n + 3) & ~3));
     u32 *gate = reinterpret_cast<u32 *>(rowflag + align_up((size_t)rows, 64));
     u32 *listbuf = gate + 16;                                         // a list of set-aside keys per workgroup of the first launch
     // the second launch's own blocks (totals of the flagged rows), 16-byte aligned, behind the lists; gate[2]: arrival counter
@@ -1213,7 +1215,7 @@ int launch_rank_bucket_two_level(const double *Y, i64 n, i64 row0, i64 rows, u64
     const int G2 = G < cus ? G : cus;
 #define RB_SEL(E_) case E_: return launch_bucket_sel_cfg<E_, 14>(Y, n, row0, rows, partial, G2, rowflag, gate, epoch, out, G, listbuf, fblocks, gate + 2, s);
     switch ((int)((n + 1023) / 1024)) {
-        RB_SEL(5) RB_SEL(6) RB_SEL(7) RB_SEL(8) RB_SEL(9) RB_SEL(11)
+        RB_SEL(3) RB_SEL(4) RB_SEL(5) RB_SEL(6) RB_SEL(7) RB_SEL(8) RB_SEL(9) RB_SEL(11)
         case 10: return launch_bucket_sel_cfg<10, 15>(Y, n, row0, rows, partial, G2, rowflag, gate, epoch, out, G, listbuf, fblocks, gate + 2, s);
     }
 #undef RB_SEL

@@ -1,4 +1,4 @@
-// mbd_rank_bucket32.hip -- K1+K2 bucket ranking on 32-bit key images, TWO workgroups per CU (J = 2, 4096 < n <= 11264).
+// mbd_rank_bucket32.hip -- K1+K2 bucket ranking on 32-bit key images, TWO workgroups per CU (J = 2, 3072 < n <= 11264).
 //
 // Same integers as rank_bucket_kernel (mbd_rank_bucket.hip), the pairwise kernel and the reference's enumeration
 // (_functional.py:246-251, _containment.py:75-77).  The fp64 kernel keeps one row per CU in LDS and its five
@@ -29,6 +29,9 @@ namespace sd {
 #ifndef R32_PRIO_LDS
 #define R32_PRIO_LDS 2                           // s_setprio in the load / histogram / prefix / scatter phases (issue on arrival)
 #define R32_PRIO_VALU 0                          // ... and in the member pass, which is bound by VALU issue
+#endif
+#ifndef R32_MIN_N
+#define R32_MIN_N 3072                           // the two-launch path is used above this n (measured: -10 % at 4 096, nothing at 3 072)
 #endif
 #ifndef R32_LNB
 #define R32_LNB 14                               // 16 384 buckets: histogram 32 KiB
@@ -469,7 +472,7 @@ __global__ __launch_bounds__(R32_NT, 4) void rank_bucket32_kernel(const double *
         for (i64 rr = r + (i64)t * gridDim.x; rr < rows; rr += (i64)NT * gridDim.x) rowflag[rr] = 1;   // rows left behind
     }
     if (t == 0 && nbad) *gate = epoch;
-    u32 *P = partial + (size_t)blockIdx.x * n;
+    u32 *P = partial + (size_t)blockIdx.x * C::al4(n);               // blocks on 16-byte boundaries whatever n
 #pragma unroll
     for (int e = 0; e < E; ++e)
         if (e < E - 2 || t + e * NT < n) P[t + e * NT] = acc[e];
@@ -499,7 +502,7 @@ __global__ __launch_bounds__(R32_NT, 4) void rank_bucket32_kernel(const double *
 bool rank_bucket32_supported(i64 n, i64 rows, int cus) {
     // u32 totals per workgroup, for this kernel's workgroups and for the fp64 kernel's when every row is handed over
     const u64 per = (u64)((rows + cus - 1) / cus) * (u64)n * (u64)n;
-    return n > 4096 && n <= 11264 && rows >= cus && rows <= 4096 && per < ((u64)1 << 32) && xswitch("SD_RB_NO32") == 0;
+    return n > R32_MIN_N && n <= 11264 && rows >= cus && rows <= 4096 && per < ((u64)1 << 32) && xswitch("SD_RB_NO32") == 0;
 }
 
 size_t rank_bucket32_extra_bytes(i64 rows) { return align_up((size_t)rows + 64, 256); }
@@ -524,6 +527,8 @@ size_t rank_bucket32_list_bytes(int G) { return (size_t)G * R32_LIST_WORDS * 4 +
 int launch_rank_bucket32(const double *Y, i64 n, i64 row0, i64 rows, u32 *partial, unsigned char *rowflag, u32 *gate, u32 epoch,
                          u64 *out_zero, u32 *listbuf, int G, hipStream_t s) {
     switch ((int)((n + 1023) / 1024)) {
+        case 3: return launch32_cfg<6>(Y, n, row0, rows, partial, rowflag, gate, epoch, out_zero, listbuf, G, s);
+        case 4: return launch32_cfg<8>(Y, n, row0, rows, partial, rowflag, gate, epoch, out_zero, listbuf, G, s);
         case 5: return launch32_cfg<10>(Y, n, row0, rows, partial, rowflag, gate, epoch, out_zero, listbuf, G, s);
         case 6: return launch32_cfg<12>(Y, n, row0, rows, partial, rowflag, gate, epoch, out_zero, listbuf, G, s);
         case 7: return launch32_cfg<14>(Y, n, row0, rows, partial, rowflag, gate, epoch, out_zero, listbuf, G, s);
@@ -532,7 +537,7 @@ int launch_rank_bucket32(const double *Y, i64 n, i64 row0, i64 rows, u32 *partia
         case 10: return launch32_cfg<20>(Y, n, row0, rows, partial, rowflag, gate, epoch, out_zero, listbuf, G, s);
         case 11: return launch32_cfg<22>(Y, n, row0, rows, partial, rowflag, gate, epoch, out_zero, listbuf, G, s);
     }
-    return fail(SD_ERR_UNSUPPORTED, "bucket32 kernel covers 4096 < n <= 11264");
+    return fail(SD_ERR_UNSUPPORTED, "bucket32 kernel covers 3072 < n <= 11264");
 }
 
 u32 rank_bucket32_epoch() {

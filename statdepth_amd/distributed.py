@@ -214,6 +214,39 @@ def sharded_mbd_counts_time(X_loc, J=2, algo="auto", group=None, sizes=None, _co
     return part[offsets[rank]:offsets[rank + 1]].clone()
 
 
+# Measured single-GPU rates of the rank routes (keys ranked per second, MI355X) and of the pairwise
+# kernel (target x curve x timepoint triples per second); xGMI: one link per peer, ~50 GB/s per direction sustained.
+_RANK_KEYS_PER_S = ((16384, 2.1e11), (40960, 1.0e11), (1 << 62, 8.3e10))
+_PAIR_TRIPLES_PER_S = 8.3e12
+_LINK_BYTES_PER_S = 50e9
+
+
+def mode_cost_model(T, n_loc, world, J=2, algo="auto"):
+    """Estimated seconds per call of the two decompositions on `world` GPUs of one node, exchange included.
+
+    time:    all-to-all (every rank sends (world-1)/world of its block, one link per peer) + ranking T/world rows of all n
+             curves + reduce-scatter of the int64 totals.
+    targets: all-gather of the curve blocks (every rank receives world-1 blocks, one link per peer) + either ranking ALL T
+             rows (the rank kernels rank whole rows whoever the targets are) or the pairwise kernel on its own targets.
+    Returns {"time": s, "targets": s, "choice": ...}; the choice is what mode="auto" takes."""
+    n = n_loc * world
+    rank_ok = J <= 3 and algo != "pairwise"
+
+    def rank_s(rows):
+        rate = next(r for cap, r in _RANK_KEYS_PER_S if n <= cap)
+        return rows * n / rate
+    peers = max(1, world - 1)
+    t_time = None
+    if rank_ok and T >= world:
+        xch = 0.0 if world == 1 else (8.0 * T * n_loc / world) / _LINK_BYTES_PER_S      # per link, links in parallel
+        red = 0.0 if world == 1 else (8.0 * n * (J - 1) / world) / _LINK_BYTES_PER_S
+        t_time = xch + rank_s((T + world - 1) // world) + red
+    gat = 0.0 if world == 1 else (8.0 * T * n_loc) / _LINK_BYTES_PER_S                  # one block per link
+    t_tg = gat + (rank_s(T) if rank_ok else T * float(n) * n_loc / _PAIR_TRIPLES_PER_S)
+    choice = "time" if (t_time is not None and t_time <= t_tg) else "targets"
+    return {"time": t_time, "targets": t_tg, "choice": choice, "peers": peers}
+
+
 def sharded_mbd_counts(X_loc, J=2, algo="auto", group=None, gather_result=False, sizes=None, mode="auto",
                        _compute=None, _compute_all=None, _force_exchange=False):
     """MBD containment totals of this rank's curves against the union of all ranks' curves.
@@ -231,7 +264,8 @@ def sharded_mbd_counts(X_loc, J=2, algo="auto", group=None, gather_result=False,
     rank = dist.get_rank(group)
     world = dist.get_world_size(group)
     if mode == "auto":
-        mode = "time" if (J <= 3 and algo != "pairwise" and X_loc.shape[0] >= world) else "targets"
+        # every rank evaluates the same model on the same numbers (T, its block size, the world size): the same choice
+        mode = mode_cost_model(int(X_loc.shape[0]), int(X_loc.shape[1]), world, J, algo)["choice"]
     if mode == "time":
         sizes = block_sizes(X_loc, group, sizes)
         local = sharded_mbd_counts_time(X_loc, J=J, algo=algo, group=group, sizes=sizes, _compute_all=_compute_all,

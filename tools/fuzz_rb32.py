@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Differential fuzz of the two-launch bucket path (rank_bucket32_kernel + rank_bucket_kernel's SEL form; 4096 < n <= 11264,
-n % 4 == 0, 256 <= T <= 4096, every curve a target) against the pairwise kernel (independent code) on the GPU box:
+"""Differential fuzz of the two-launch bucket path (rank_bucket32_kernel + rank_bucket_kernel's SEL form; 3072 < n <= 11264,
+256 <= T <= 4096, every curve a target) against the pairwise kernel (independent code) on the GPU box:
 continuous rows, image collisions (values a hair apart), equal values, duplicated curves, quantised rows, NaN / inf rows,
 outlying curves, constant rows.  usage: fuzz_rb32.py [cases] [seed]"""
 import os, sys
@@ -12,7 +12,7 @@ cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 bad = 0
 for c in range(cases):
-    n = 4 * int(rng.integers(1025, 2817))
+    n = int(rng.integers(3073, 11265))
     T = int(rng.choice([256, 257, 300, 511, 512, 513, 700, 1024]))
     kind = rng.choice(["walk", "normal", "round1", "round2", "ints", "lognormal", "mixed"])
     X = rng.normal(size=(T, n))
