@@ -32,6 +32,11 @@ namespace sd {
 
 int launch_rank_bucket_image(const double *Y, i64 n, i64 row0, i64 rows, u32 *AB, u32 *nnan, hipStream_t s);   // mbd_rank_bucket.hip
 int launch_rank_medium_image(const double *Y, i64 n, i64 row0, i64 rows, u32 *AB, u32 *nnan, hipStream_t s);   // ... its two-block form
+int launch_rank_big_image(const double *Y, i64 T, i64 n, u32 *img, u32 *nnan, void *ws, size_t ws_bytes, hipStream_t s);   // mbd_rank_big.hip
+// 32 767 < n <= 131 071: 32-bit ranks from the large-n route's B image (strict_masks_rank32_kernel)
+static inline bool strict_rank32_applies(i64 T, i64 n, int J) {
+    return J == 2 && n > 32767 && n <= 131071 && mbd_rank_big_supported(T, n, 2);
+}
 constexpr i64 ST_RANK_MAXN = 32767;          // ranks below 2^15 (two per register in the mask kernel); images: bucket kernel up to
                                              // 16 384 curves, its column-block form beyond
 
@@ -68,7 +73,9 @@ static size_t strict_ws_for_batch(i64 T, i64 n, i64 b) {
            align_up((size_t)b * (strict_table_slots(n) * 16 + 16 + ((n + 63) / 64) * 8), 256) +
            align_up((size_t)((T + 31) / 32) * 4, 256) + align_up((size_t)b * ((T + 31) / 32) * 256, 256) +
            align_up((size_t)b * n * 8, 256) + align_up((size_t)b * n, 256) + align_up((size_t)(b + 1) * 4, 256) +
-           (n <= ST_RANK_MAXN ? align_up((size_t)T * n * 4, 256) + 2 * align_up((size_t)T * 4, 256) : 0) + 2560;
+           (n <= ST_RANK_MAXN ? align_up((size_t)T * n * 4, 256) + 2 * align_up((size_t)T * 4, 256) : 0) +
+           (strict_rank32_applies(T, n, 2) ? align_up((size_t)T * n * 4, 256) + 2 * align_up((size_t)T * 4, 256) +
+                                                 align_up(mbd_rank_big_workspace_bytes(T, n, 2), 256) : 0) + 2560;
 }
 
 // The RECOMMENDED size (batches of strict_batch targets).  The launchers take any workspace that holds a batch of one
@@ -422,6 +429,101 @@ __global__ __launch_bounds__(ST_THREADS) void strict_masks_rank_kernel(
         }
         qv = qn;
         b = bn;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// The same masks from 32-BIT ranks (32 767 < n <= 131 071: config 3's size).  R[t][i] = the large-n route's B word
+// (mbd_rank_big.hip, launch_rank_big_image): curves strictly below curve i at t, bit 31 set when the curve ties with
+// another one there, 0xFFFFFFFF for NaN.  B is order- and tie-preserving, so x_i > x_q <=> B_i > B_q <=> bit 31 of
+// B_q - B_i (ranks < 2^31): v_sub_u32 + v_alignbit_b32 per (timepoint, direction) against two half-rate v_cmp_f64 +
+// two v_cndmask + v_or of the fp64 kernel.  Thread = curve, block = 256 curves x one word x 32 targets, as above.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(ST_THREADS) void strict_row_ties32_kernel(const u32 *__restrict__ R, i64 n, u32 *__restrict__ tiemask) {
+    const i64 t = blockIdx.x;
+    bool tie = false;
+    for (i64 i = threadIdx.x; i < n; i += ST_THREADS) {
+        const u32 w = R[t * n + i];
+        tie |= w != ST_RANK_NAN && (w >> 31) != 0;
+    }
+    if (__syncthreads_or(tie) && threadIdx.x == 0) atomicOr(&tiemask[t >> 5], 1u << (t & 31));
+}
+
+// Rt[b][t] = the target's rank at t (tie bit cleared; 0 beyond T and for NaN, which is noted in xnan)
+__global__ __launch_bounds__(ST_THREADS) void strict_gather_rank32_targets_kernel(
+    const u32 *__restrict__ R, i64 T, i64 n, const i64 *__restrict__ targets, i64 q0, u32 *__restrict__ Rt,
+    u32 *__restrict__ xnan) {
+    const i64 b = blockIdx.x;
+    const i64 tg = targets ? targets[q0 + b] : q0 + b;
+    const i64 Tp = ((T + 31) / 32) * 32;
+    bool isn = false;
+    for (i64 t = threadIdx.x; t < Tp; t += ST_THREADS) {
+        const u32 w = t < T ? R[t * n + tg] : 0u;
+        isn |= w == ST_RANK_NAN;
+        Rt[b * Tp + t] = w == ST_RANK_NAN ? 0u : (w & 0x7FFFFFFFu);
+    }
+    if (__syncthreads_or(isn) && threadIdx.x == 0) xnan[b] = 1;
+}
+
+// grid = (ceil(n / 256), W32, ceil(nb / ST_TG))
+__global__ __launch_bounds__(ST_THREADS) void strict_masks_rank32_kernel(
+    const u32 *__restrict__ R, const u32 *__restrict__ Rt, i64 T, i64 n, i64 nb, StrictMaskOut o) {
+    const i64 cnt = o.dlist ? (i64)*o.dcount : nb;
+    const i64 z0 = (i64)blockIdx.z * ST_TG;
+    if (z0 >= cnt) return;
+    const i64 zend = z0 + ST_TG < cnt ? z0 + ST_TG : cnt;
+    const i64 i = (i64)blockIdx.x * ST_THREADS + threadIdx.x;
+    const int k = blockIdx.y;
+    const int W32 = (int)((T + 31) / 32);
+    const i64 t0 = (i64)k * 32;
+    const int tl = (int)(T - t0 < 32 ? T - t0 : 32);
+    const u32 valid = tl == 32 ? 0xFFFFFFFFu : ((1u << tl) - 1u);
+    u32 x[32];
+    u32 nanbits = 0;
+#pragma unroll
+    for (int t = 0; t < 32; ++t) {
+        const u32 w = (i < n && t < tl) ? R[(t0 + t) * n + i] : 0u;
+        const bool isn = w == ST_RANK_NAN;
+        nanbits |= isn ? (1u << t) : 0u;
+        x[t] = isn ? 0u : (w & 0x7FFFFFFFu);
+    }
+    const bool un_only = o.dflag != nullptr && tl == 32 && o.cmask[k] == 0;
+    const bool no_ties = un_only && o.tiemask != nullptr && o.tiemask[k] == 0;
+    typedef u32 u32x16 __attribute__((ext_vector_type(16)));
+    for (i64 z = z0; z < zend; ++z) {
+        const i64 b = o.dlist ? (i64)o.dlist[z] : z;
+        const u32 *qp = Rt + (b * W32 + k) * 32;                      // wave-uniform: two s_load_dwordx16
+        const u32x16 qa = *reinterpret_cast<const u32x16 *>(qp), qb = *reinterpret_cast<const u32x16 *>(qp + 16);
+        u32 un = 0, dn = 0;
+        if (no_ties) {                                                // block-uniform: continuous data, everywhere
+#pragma unroll
+            for (int t = 31; t >= 0; --t) un = __builtin_amdgcn_alignbit(un, (t < 16 ? qa[t] : qb[t - 16]) - x[t], 31);
+            if (i < n) {
+                o.m32[((size_t)b * 2 * W32 + k) * n + i] = un | nanbits;
+                if (nanbits) o.dflag[(size_t)b * n + i] = 1;
+            }
+        } else if (un_only) {                                         // block-uniform: of DN only "is there a tie" is wanted
+            u32 mn = 0xFFFFFFFFu;
+#pragma unroll
+            for (int t = 31; t >= 0; --t) {
+                const u32 q = t < 16 ? qa[t] : qb[t - 16];
+                un = __builtin_amdgcn_alignbit(un, q - x[t], 31);
+                const u32 e = q ^ x[t];
+                mn = mn < e ? mn : e;
+            }
+            if (i < n) {
+                o.m32[((size_t)b * 2 * W32 + k) * n + i] = un | nanbits;
+                if (mn == 0u || nanbits) o.dflag[(size_t)b * n + i] = 1;
+            }
+        } else {
+#pragma unroll
+            for (int t = 31; t >= 0; --t) {
+                const u32 q = t < 16 ? qa[t] : qb[t - 16];
+                un = __builtin_amdgcn_alignbit(un, q - x[t], 31);     // x above q
+                dn = __builtin_amdgcn_alignbit(dn, x[t] - q, 31);     // x below q
+            }
+            strict_store_masks(o, b, k, W32, n, i, (un | nanbits) & valid, (dn | nanbits) & valid, valid);
+        }
     }
 }
 
@@ -1299,7 +1401,18 @@ static int launch_bd_strict_impl(const double *Y, i64 T, i64 n, const i64 *targe
     u32 *dcount = dlist + B;
     // cross-check builds, SD_STRICT_FP64_MASKS = 1: masks from the fp64 values at any n
     const bool rankmasks = !Q && n >= 2 && n <= ST_RANK_MAXN && J == 2 && xswitch("SD_STRICT_V1") != 1 && xswitch("SD_STRICT_FP64_MASKS") != 1;
+    const bool rank32 = !Q && strict_rank32_applies(T, n, J) && xswitch("SD_STRICT_V1") != 1 && xswitch("SD_STRICT_FP64_MASKS") != 1;
     u32 *R = nullptr, *rnan = nullptr, *tiemask = nullptr;
+    void *bigws = nullptr;
+    size_t bigws_bytes = 0;
+    if (rank32) {
+        R = (u32 *)cv.take((size_t)T * n * 4);
+        rnan = (u32 *)cv.take((size_t)T * 4);
+        tiemask = (u32 *)cv.take((size_t)((T + 31) / 32) * 4);
+        bigws_bytes = mbd_rank_big_workspace_bytes(T, n, 2);
+        bigws = cv.take(bigws_bytes);
+        if (!R || !rnan || !tiemask || !bigws) return fail(SD_ERR_WORKSPACE, "strict-depth workspace too small");
+    }
     if (rankmasks) {
         R = (u32 *)cv.take((size_t)T * n * 4);
         rnan = (u32 *)cv.take((size_t)T * 4);
@@ -1339,6 +1452,12 @@ static int launch_bd_strict_impl(const double *Y, i64 T, i64 n, const i64 *targe
         hipLaunchKernelGGL(strict_row_ties_kernel, dim3((unsigned)T), dim3(ST_THREADS), 0, s, (const u32 *)R, (const u32 *)rnan, n,
                            tiemask);
     }
+    if (rank32) {
+        int rc = launch_rank_big_image(Y, T, n, R, rnan, bigws, bigws_bytes, s);
+        if (rc) return rc;
+        SD_HIP(hipMemsetAsync(tiemask, 0, (size_t)((T + 31) / 32) * 4, s));
+        hipLaunchKernelGGL(strict_row_ties32_kernel, dim3((unsigned)T), dim3(ST_THREADS), 0, s, (const u32 *)R, n, tiemask);
+    }
     for (i64 q0 = 0; q0 < m; q0 += B) {
         i64 nb = m - q0 < B ? m - q0 : B;
         SD_HIP(hipMemsetAsync(xnan, 0, (size_t)nb * 4, s));
@@ -1358,6 +1477,10 @@ static int launch_bd_strict_impl(const double *Y, i64 T, i64 n, const i64 *targe
                 hipLaunchKernelGGL(strict_gather_rank_targets_kernel, dim3((unsigned)nb), dim3(ST_THREADS), 0, s, (const u32 *)R, T, n,
                                    targets, q0, (u32 *)Yt, xnan);
                 hipLaunchKernelGGL(strict_masks_rank_kernel, g1b, dim3(ST_THREADS), 0, s, (const u32 *)R, (const u32 *)Yt, T, n, nb, mo);
+            } else if (rank32) {
+                hipLaunchKernelGGL(strict_gather_rank32_targets_kernel, dim3((unsigned)nb), dim3(ST_THREADS), 0, s, (const u32 *)R, T, n,
+                                   targets, q0, (u32 *)Yt, xnan);
+                hipLaunchKernelGGL(strict_masks_rank32_kernel, g1b, dim3(ST_THREADS), 0, s, (const u32 *)R, (const u32 *)Yt, T, n, nb, mo);
             } else {
                 hipLaunchKernelGGL(strict_gather_targets_kernel, dim3((unsigned)nb), dim3(ST_THREADS), 0, s, Y, T, n, targets, q0, Q, m,
                                    Yt, xnan);
@@ -1390,6 +1513,9 @@ static int launch_bd_strict_impl(const double *Y, i64 T, i64 n, const i64 *targe
                     if (rankmasks)
                         hipLaunchKernelGGL(strict_masks_rank_kernel, g1b, dim3(ST_THREADS), 0, s, (const u32 *)R, (const u32 *)Yt, T, n, nb,
                                            mf);
+                    else if (rank32)
+                        hipLaunchKernelGGL(strict_masks_rank32_kernel, g1b, dim3(ST_THREADS), 0, s, (const u32 *)R, (const u32 *)Yt, T, n,
+                                           nb, mf);
                     else
                         hipLaunchKernelGGL(strict_masks2_kernel, g1b, dim3(ST_THREADS), 0, s, Y, (const double *)Yt, T, n, nb, mf);
                 }

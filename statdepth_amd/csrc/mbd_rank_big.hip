@@ -1544,8 +1544,22 @@ size_t mbd_rank_big_workspace_bytes(i64 T, i64 n, int J) {
     return big_plan(T, n).total + 1024;
 }
 
+// img_out != nullptr: no fold -- the B words of every (row, curve) go to img_out[T][n] (bit 31: the curve ties with another
+// one at this timepoint; 0xFFFFFFFF: NaN) and the rows' NaN counts to nnan_out[T]: the strict path's rank image for n > 32 767
+static int big_run(const double *Y, i64 T, i64 n, const i64 *targets, i64 tbegin, i64 m, int J, u64 *out, void *ws,
+                   size_t ws_bytes, hipStream_t s, u32 *img_out, u32 *nnan_out);
+
 int launch_mbd_rank_big(const double *Y, i64 T, i64 n, const i64 *targets, i64 tbegin, i64 m, int J,
                         u64 *out, void *ws, size_t ws_bytes, hipStream_t s) {
+    return big_run(Y, T, n, targets, tbegin, m, J, out, ws, ws_bytes, s, nullptr, nullptr);
+}
+
+int launch_rank_big_image(const double *Y, i64 T, i64 n, u32 *img, u32 *nnan, void *ws, size_t ws_bytes, hipStream_t s) {
+    return big_run(Y, T, n, nullptr, 0, n, 2, nullptr, ws, ws_bytes, s, img, nnan);
+}
+
+static int big_run(const double *Y, i64 T, i64 n, const i64 *targets, i64 tbegin, i64 m, int J, u64 *out, void *ws,
+                   size_t ws_bytes, hipStream_t s, u32 *img_out, u32 *nnan_out) {
     if (!mbd_rank_big_supported(T, n, J)) return fail(SD_ERR_UNSUPPORTED, "large-n rank kernels cover n > 16384");
     const BigPlan p = big_plan(T, n);
     if (!ws || ws_bytes < p.total) return fail(SD_ERR_WORKSPACE, "large-n rank workspace too small");
@@ -1622,6 +1636,7 @@ int launch_mbd_rank_big(const double *Y, i64 T, i64 n, const i64 *targets, i64 t
         const u32 *fallback_rows = nullptr;                  // chunked route: every row
         const u32 *nn_for_fold = nanf;
         const u32 *gate_o = nullptr;                         // no gate: the chunk kernels look at every row flag
+        if (img_out) ab.B = img_out + (size_t)row0 * n;      // image mode: the B words straight into the caller's image
         u32 epoch = ++epoch_counter;
         if (epoch == 0) epoch = ++epoch_counter;
         if (!buckets || gen2) SD_HIP(hipMemsetAsync(zb, 0, p.zero_bytes, s));      // (the third generation's S3 zeroes)
@@ -1691,6 +1706,10 @@ int launch_mbd_rank_big(const double *Y, i64 T, i64 n, const i64 *targets, i64 t
         hipLaunchKernelGGL(k_cq, dim3((unsigned)(rgroups * p.nch)), dim3(BIG_NT), BigCfg::LDS_BYTES, s, Y, n, row0, rows,
                            (const double *)sorted, p.sstride, (const u32 *)nanf, (int)p.nch, fallback_rows, gate_o, epoch, ab);
         SD_HIP(hipGetLastError());
+        if (img_out) {
+            SD_HIP(hipMemcpyAsync(nnan_out + row0, nn_for_fold, (size_t)rows * 4, hipMemcpyDeviceToDevice, s));
+            continue;
+        }
         const int first = row0 == 0;
         if (!targets && (n & 3) == 0 && (tbegin & 3) == 0 && J <= 3) {
             dim3 grid4((unsigned)((m + 127) / 128));
