@@ -842,6 +842,15 @@ __global__ __launch_bounds__(ST_ML_THREADS) void strict_match_lds_kernel(
     __syncthreads();
     u64 acc = 0;
     u32 z0 = 0, z1 = 0, nd = 0;
+    // More curves than the table takes at a load of 0.8 (n > 13 107: slots = 16 384): the 2 x 8 KiB filter would fill up
+    // (at n = 10^5 half of the crossing curves passed it and the table was filled in 5 - 6 rounds, every round a pass over the
+    // digests: 0.52 of config-3-size's 0.83 s).  Then the whole table area serves as the filter first -- 2^19 bits per
+    // side, load < 0.13 -- the few curves that pass it are remembered as one bit per (thread, iteration) in registers, and
+    // the table is built from them alone: three passes over the digests, no rounds.
+    const bool must_count = (i64)n * 5 > (i64)slots * 4;
+    const bool bigf = must_count && slots == 16384;                         // block-uniform
+    u32 *fbits = bigf ? tabl : seen;                                        // [2][FB / 32]
+    const u32 FB = bigf ? (1u << 19) : (u32)ST_ML_SEEN;
     // Pass 1: dirty curves, the two empty-mask counts, and one bit per (side, digest): a curve can only pair with a
     // curve whose canonical mask -- hence digest -- it shares on the OTHER side, and in continuous data hardly any
     // digest occurs on both sides.  One LDS atomic per curve, no probing.
@@ -860,8 +869,8 @@ __global__ __launch_bounds__(ST_ML_THREADS) void strict_match_lds_kernel(
                 z0 += side == 0;
                 z1 += side == 1;
             } else {
-                const u32 bit = (u32)(strict_spread(hf) >> 24) & (ST_ML_SEEN - 1);
-                atomicOr(&seen[side * (ST_ML_SEEN / 32) + (bit >> 5)], 1u << (bit & 31));
+                const u32 bit = (u32)(strict_spread(hf) >> 24) & (FB - 1);
+                atomicOr(&fbits[side * (FB / 32) + (bit >> 5)], 1u << (bit & 31));
             }
         }
     }
@@ -869,17 +878,26 @@ __global__ __launch_bounds__(ST_ML_THREADS) void strict_match_lds_kernel(
     // How many candidates?  (The table takes 0.6 of its slots per round; see below.)  Not counted when even all n curves
     // would fit at a load of 0.8.
     int cand = 0;
-    const bool must_count = (i64)n * 5 > (i64)slots * 4;
-    for (i64 a0 = 0; a0 < n && must_count; a0 += ST_ML_THREADS) {
-        const i64 a = a0 + tid;
-        const u64 hf = a < n ? hb[a] : 0;
-        bool c = false;
-        if (a < n && a != tg && (hf & 3) == 3) {
-            const u32 side = (u32)(hf >> 2) & 1u;
-            const u32 bit = (u32)(strict_spread(hf) >> 24) & (ST_ML_SEEN - 1);
-            c = (seen[(1u - side) * (ST_ML_SEEN / 32) + (bit >> 5)] >> (bit & 31)) & 1u;
+    u64 f01 = 0, f23 = 0;                                                   // bigf: this thread's candidates, bit = iteration (n < 2^17)
+    {
+        int it = 0;
+        for (i64 a0 = 0; a0 < n && must_count; a0 += ST_ML_THREADS, ++it) {
+            const i64 a = a0 + tid;
+            const u64 hf = a < n ? hb[a] : 0;
+            bool c = false;
+            if (a < n && a != tg && (hf & 3) == 3) {
+                const u32 side = (u32)(hf >> 2) & 1u;
+                const u32 bit = (u32)(strict_spread(hf) >> 24) & (FB - 1);
+                c = (fbits[(1u - side) * (FB / 32) + (bit >> 5)] >> (bit & 31)) & 1u;
+            }
+            if (c) { if (it < 64) f01 |= 1ull << it; else f23 |= 1ull << (it - 64); }
+            cand += __syncthreads_count(c);
         }
-        cand += __syncthreads_count(c);
+    }
+    if (bigf) {                                                             // the filter has served: its area becomes the table
+        __syncthreads();
+        for (int e = tid; e < 2 * slots; e += ST_ML_THREADS) tabl[e] = 0;
+        __syncthreads();
     }
     // More candidates than the table takes (n in the tens of thousands: the filter fills up and lets half of the crossing
     // curves through): the digests are dealt into `rounds` classes by hash bits of their own and the table is filled
@@ -895,15 +913,17 @@ __global__ __launch_bounds__(ST_ML_THREADS) void strict_match_lds_kernel(
         __syncthreads();
     }
     bool stuck = false;
-    for (i64 a0 = 0; a0 < n; a0 += ST_ML_THREADS) {
+    int it = 0;
+    for (i64 a0 = 0; a0 < n; a0 += ST_ML_THREADS, ++it) {
         const i64 a = a0 + tid;
+        if (bigf && !(((it < 64 ? f01 >> it : f23 >> (it - 64))) & 1ull)) continue;   // not a candidate: its digest is not even read
         const u64 hf = a < n ? hb[a] : 0;
         if (a < n && a != tg && (hf & 3) == 3) {
             const u32 side = (u32)(hf >> 2) & 1u;
             const u64 h = strict_spread(hf);
             const u32 bit = (u32)(h >> 24) & (ST_ML_SEEN - 1);
             if ((int)((u32)(h >> 53) % (u32)rounds) == rd &&
-                ((seen[(1u - side) * (ST_ML_SEEN / 32) + (bit >> 5)] >> (bit & 31)) & 1u)) {
+                (bigf || ((seen[(1u - side) * (ST_ML_SEEN / 32) + (bit >> 5)] >> (bit & 31)) & 1u))) {
                 const u32 tag = ((u32)(h >> 40) & 0x1FFFu) | 0x2000u;       // 14 bits, never zero
                 const u32 mine = (tag << 18) | (side << 17) | (u32)a;       // a < 2^17
                 int slot = (int)(h & (u64)(slots - 1));
