@@ -55,7 +55,7 @@ static inline i64 strict_table_slots(i64 n) {
 static inline bool strict_match_applies(i64 T, i64 n, int J) { return J == 2 && (T + 31) / 32 <= 65535 && n <= ST_MATCH_MAXN; }
 
 static i64 strict_batch(i64 T, i64 n, i64 m) {
-    size_t per = (size_t)n * 2 * strict_words(T) * 8 + (size_t)strict_table_slots(n) * 16 + 20 + (size_t)((n + 63) / 64) * 8 + (size_t)((T + 31) / 32) * 256 + (size_t)n * 9;
+    size_t per = (size_t)n * 2 * strict_words(T) * 8 + (size_t)strict_table_slots(n) * 16 + 20 + (size_t)((n + 63) / 64) * 8 + (size_t)((T + 31) / 32) * 256 + (size_t)n * 13 + 16;
     i64 b = (i64)(((size_t)2048 << 20) / (per ? per : 1));   // up to 2 GiB of masks and tables per batch ...
     if (b < 1024) {                                           // ... or 16 GiB when that is what 1024 targets take: the matching
         const i64 b16 = (i64)(((size_t)16384 << 20) / (per ? per : 1));   // kernel runs one workgroup per target
@@ -73,6 +73,7 @@ static size_t strict_ws_for_batch(i64 T, i64 n, i64 b) {
            align_up((size_t)b * (strict_table_slots(n) * 16 + 16 + ((n + 63) / 64) * 8), 256) +
            align_up((size_t)((T + 31) / 32) * 4, 256) + align_up((size_t)b * ((T + 31) / 32) * 256, 256) +
            align_up((size_t)b * n * 8, 256) + align_up((size_t)b * n, 256) + align_up((size_t)(b + 1) * 4, 256) +
+           align_up((size_t)b * (n + 4) * 4, 256) +
            (n <= ST_RANK_MAXN ? align_up((size_t)T * n * 4, 256) + 2 * align_up((size_t)T * 4, 256) : 0) +
            (strict_rank32_applies(T, n, 2) ? align_up((size_t)T * n * 4, 256) + 2 * align_up((size_t)T * 4, 256) +
                                                  align_up(mbd_rank_big_workspace_bytes(T, n, 2), 256) : 0) + 2560;
@@ -725,6 +726,138 @@ __device__ __forceinline__ void strict_pairs2_target(const u32 *__restrict__ m32
 // Without matching: grid = (a tiles, b chunks, nb), block z = target z.  With matching: grid.z is a fixed number of
 // layers that share out the batch's targets WITH dirty curves (dlist, *dcount: appended by the matching kernels) --
 // continuous data has none, and a grid over all targets would cost more in empty blocks than everything else here.
+// The same count over the target's LIST of curves that can be in a pair the matching has not counted (strict_match_lds_kernel
+// writes it): the dirty curves (ties / NaN with the target; bit 31 of their entry) and the clean curves that cross the target.
+// A clean curve that stays below (above) the target throughout contains it with a dirty curve a exactly when a is never
+// below (never above) it -- DN_a (UN_a) empty -- so those partners, the bulk of banded or quantised data, are counted as
+// z0 (z1) per dirty curve without a look at their masks.  ilist[b]: {entries, z0, z1, -, entry...}; the a < c rule runs
+// on list positions.
+__device__ __forceinline__ void strict_pairs3_target(const u32 *__restrict__ m32, i64 T, i64 n, i64 q0,
+                                                     const u32 *__restrict__ ilist, u64 *__restrict__ out, int jcols,
+                                                     const i64 b) {
+    __shared__ u64 scratch[ST_THREADS / 64];
+    __shared__ u32 orparts[ST_THREADS / 64][2][ST_SUB];   // per wave: OR of its quarter of partner j's UN / DN words
+    __shared__ __attribute__((aligned(16))) u32 cm[ST_SUB][2 * ST_W32 + 4];   // partner j: UN words 0..31, DN words 0..31 (zero
+                                                                                // beyond W32); rows padded by 16 bytes: the survivors'
+                                                                                // per-lane rows fall on different banks
+    __shared__ u32 sidx[ST_SUB];                            // the sub-chunk's curve indices (bit 31: dirty)
+    const i64 q = q0 + b;
+    const u32 *lst = ilist + (size_t)b * (n + 4);
+    const i64 len_l = (i64)lst[0];
+    const u64 z0 = lst[1], z1 = lst[2];
+    lst += 4;
+    const i64 apos = (i64)blockIdx.x * ST_THREADS + threadIdx.x;
+    const i64 b0 = (i64)blockIdx.y * ST_BCHUNK;
+    const i64 b1 = b0 + ST_BCHUNK < len_l ? b0 + ST_BCHUNK : len_l;
+    const i64 amin = (i64)blockIdx.x * ST_THREADS;
+    if (amin >= len_l) return;
+    const bool closed = blockIdx.y == 0;                   // this block also adds its lanes' pairs with the z0 / z1 curves
+    if (b1 - 1 <= amin && !closed) return;     // whole chunk at or below the tile: no a < b pair
+    const int W32 = (int)((T + 31) / 32);
+    const u32 *mb = m32 + (size_t)b * 2 * W32 * n;
+    const bool alive = apos < len_l;
+    const u32 ent = alive ? lst[apos] : 0u;
+    const i64 a = (i64)(ent & 0x7FFFFFFFu);
+    u32 un[ST_W32], dn[ST_W32];
+#pragma unroll
+    for (int w = 0; w < ST_W32; ++w) {
+        un[w] = (alive && w < W32) ? mb[(size_t)w * n + a] : 0u;
+        dn[w] = (alive && w < W32) ? mb[(size_t)(W32 + w) * n + a] : 0u;
+    }
+    // a curve that is never above the target (UN empty) cannot conflict with one that is never below it (DN empty):
+    // such pairs -- most of the contained pairs of banded data -- need no walk over the masks
+    u32 ora = 0, ord_ = 0;
+#pragma unroll
+    for (int w = 0; w < ST_W32; ++w) { ora |= un[w]; ord_ |= dn[w]; }
+    const bool u0a = ora == 0, d0a = ord_ == 0;
+    const bool dirty_a = alive && (ent >> 31);
+    const bool tile_dirty = __syncthreads_or(dirty_a) != 0;     // block-uniform
+    u64 good = 0;
+    if (closed && dirty_a) good += (d0a ? z0 : 0ull) + (u0a ? z1 : 0ull);
+    for (i64 s0 = b0; s0 < b1; s0 += ST_SUB) {
+        if (s0 + ST_SUB <= amin + 1) continue;                  // every partner of this sub-chunk at or below every lane's position
+        const int len = (int)(b1 - s0 < ST_SUB ? b1 - s0 : ST_SUB);
+        __syncthreads();                                        // the previous sub-chunk has been read
+        if (threadIdx.x < ST_SUB) sidx[threadIdx.x] = threadIdx.x < len ? lst[s0 + threadIdx.x] : 0u;
+        __syncthreads();
+        const u64 dsub = __ballot((int)(threadIdx.x & 63) < len && (sidx[threadIdx.x & 63] >> 31));   // dirty partners of this sub-chunk
+        if (!tile_dirty && dsub == 0) continue;                 // clean tile x clean partners: counted by the matching
+        for (int e = threadIdx.x; e < ST_SUB * 2 * ST_W32; e += ST_THREADS) {
+            const int w2 = e / ST_SUB, j = e % ST_SUB;          // consecutive threads: consecutive partners of one word
+            const int w = w2 % ST_W32;
+            u32 v = 0;
+            if (j < len && w < W32) v = mb[(size_t)(w2 < ST_W32 ? w : W32 + w) * n + (sidx[j] & 0x7FFFFFFFu)];
+            cm[j][w2] = v;
+        }
+        __syncthreads();
+        // which partners have an empty UN / DN mask: wave w ORs words 8w..8w+7 of partner j = lane, the four waves meet in LDS
+        {
+            const int j = threadIdx.x & 63, part = threadIdx.x >> 6;
+            u32 pu = 0, pd = 0;
+#pragma unroll
+            for (int w = 0; w < 8; w += 4) {
+                const uint4 cu = *reinterpret_cast<const uint4 *>(&cm[j][part * 8 + w]);
+                const uint4 cd = *reinterpret_cast<const uint4 *>(&cm[j][ST_W32 + part * 8 + w]);
+                pu |= cu.x | cu.y | cu.z | cu.w;
+                pd |= cd.x | cd.y | cd.z | cd.w;
+            }
+            orparts[part][0][j] = pu;
+            orparts[part][1][j] = pd;
+        }
+        __syncthreads();
+        u64 U0, D0;                                             // bit j: partner j has no UN / no DN bit (wave-uniform)
+        {
+            const int j = threadIdx.x & 63;
+            U0 = __ballot((orparts[0][0][j] | orparts[1][0][j] | orparts[2][0][j] | orparts[3][0][j]) == 0);
+            D0 = __ballot((orparts[0][1][j] | orparts[1][1][j] | orparts[2][1][j] | orparts[3][1][j]) == 0);
+        }
+        // ---- pass 1: first four words of every partner; survivors as bits ----
+        u64 surv = 0;
+#pragma unroll 8
+        for (int j = 0; j < ST_SUB; ++j) {
+            const uint4 cu = *reinterpret_cast<const uint4 *>(&cm[j][0]);
+            const uint4 cd = *reinterpret_cast<const uint4 *>(&cm[j][ST_W32]);
+            const u32 bad = (un[0] & cu.x) | (un[1] & cu.y) | (un[2] & cu.z) | (un[3] & cu.w) | (dn[0] & cd.x) |
+                            (dn[1] & cd.y) | (dn[2] & cd.z) | (dn[3] & cd.w);
+            surv |= (u64)(bad == 0) << j;
+        }
+        // real partners only (a curve that ties with the target everywhere has empty masks and conflicts with nothing,
+        // not even with the padding or the target's own slot): block-uniform mask; then c > a only
+        const u64 real = len == ST_SUB ? ~0ull : (((u64)1 << len) - 1);
+        surv = alive ? (surv & real) : 0;
+        if (!dirty_a) surv &= dsub;
+        const i64 jf = apos + 1 - s0;
+        surv = (jf <= 0) ? surv : (jf >= 64 ? 0 : (surv >> (int)jf) << (int)jf);
+        if (W32 <= 4) {
+            good += (u64)__popcll(surv);
+        } else {
+            // pairs that cannot conflict by class: counted without the walk
+            const u64 sure = surv & ((u0a ? D0 : 0ull) | (d0a ? U0 : 0ull));
+            good += (u64)__popcll(sure);
+            surv &= ~sure;
+            // ---- pass 2: the survivors' remaining words ----
+            while (surv) {
+                const int j = __ffsll((long long)surv) - 1;
+                surv &= surv - 1;
+                u32 bad = 0;
+#pragma unroll
+                for (int w = 4; w < ST_W32; w += 4) {                   // 16-byte LDS reads (per-lane partner j)
+                    const uint4 cu = *reinterpret_cast<const uint4 *>(&cm[j][w]);
+                    const uint4 cd = *reinterpret_cast<const uint4 *>(&cm[j][ST_W32 + w]);
+                    bad |= (un[w] & cu.x) | (un[w + 1] & cu.y) | (un[w + 2] & cu.z) | (un[w + 3] & cu.w) | (dn[w] & cd.x) |
+                           (dn[w + 1] & cd.y) | (dn[w + 2] & cd.z) | (dn[w + 3] & cd.w);
+                }
+                good += (bad == 0);
+            }
+        }
+    }
+    u64 tot = block_sum(good, scratch);
+    if (threadIdx.x == 0 && tot) atomicAdd(&out[q * jcols], tot);
+}
+
+// Without matching: grid = (a tiles, b chunks, nb), block z = target z.  With matching: grid.z is a fixed number of
+// layers that share out the batch's targets WITH dirty curves (dlist, *dcount: appended by the matching kernels) --
+// continuous data has none, and a grid over all targets would cost more in empty blocks than everything else here.
 constexpr int ST_PAIR_LAYERS = 32;
 __global__ __launch_bounds__(ST_THREADS) void strict_pairs2_kernel(
     const u32 *__restrict__ m32, i64 T, i64 n, const i64 *__restrict__ targets, i64 q0,
@@ -741,6 +874,19 @@ __global__ __launch_bounds__(ST_THREADS) void strict_pairs2_kernel(
         __syncthreads();                           // the target's shared arrays are reused by the next one
     }
 }
+
+// grid = (ceil(n / 256), ceil(n / ST_BCHUNK), layers): the targets of the matching's work list, each over its own list of
+// curves (blocks beyond a list's end leave at once)
+__global__ __launch_bounds__(ST_THREADS) void strict_pairs3_kernel(
+    const u32 *__restrict__ m32, i64 T, i64 n, i64 q0, const u32 *__restrict__ dlist, const u32 *__restrict__ dcount,
+    const u32 *__restrict__ ilist, u64 *__restrict__ out, int jcols) {
+    const u32 cnt = *dcount;
+    for (u32 zi = blockIdx.z; zi < cnt; zi += gridDim.z) {
+        strict_pairs3_target(m32, T, n, q0, ilist, out, jcols, (i64)dlist[zi]);
+        __syncthreads();                           // the target's shared arrays are reused by the next one
+    }
+}
+
 
 // ---------------------------------------------------------------------------------------------------
 // J = 2 by complement matching: O(n T) per target instead of O(n^2 T).
@@ -825,9 +971,10 @@ __global__ __launch_bounds__(ST_ML_THREADS) void strict_match_lds_kernel(
     const u32 *__restrict__ m32, const u64 *__restrict__ HF, i64 T, i64 n, const i64 *__restrict__ targets, i64 q0,
     const u32 *__restrict__ xnan, const u32 *__restrict__ cmask, u32 *__restrict__ meta, u64 *__restrict__ dbits,
     u32 *__restrict__ dlist, u32 *__restrict__ dcount, int slots, int whole_targets, int force_overflow,
-    u64 *__restrict__ out, int jcols) {
+    u64 *__restrict__ out, int jcols, u32 *__restrict__ ilist) {
     extern __shared__ u32 tabl[];                             // keys [slots] | counters [slots]
     __shared__ u64 red[ST_ML_THREADS / 64][3];
+    __shared__ u32 lcount;                                    // entries of the pair kernel's curve list so far
     const i64 b = blockIdx.x;
     if (xnan[b]) return;
     const i64 tg = targets ? targets[q0 + b] : q0 + b;
@@ -839,6 +986,8 @@ __global__ __launch_bounds__(ST_ML_THREADS) void strict_match_lds_kernel(
     u32 *cntl = tabl + slots;
     u32 *seen = cntl + slots;                                 // [2][ST_ML_SEEN / 32]: digests present on side 0 / side 1
     for (int e = tid; e < 2 * slots + 2 * (ST_ML_SEEN / 32); e += ST_ML_THREADS) tabl[e] = 0;
+    if (tid == 0) lcount = 0;
+    u32 *lst = ilist ? ilist + (size_t)b * (n + 4) + 4 : nullptr;
     __syncthreads();
     u64 acc = 0;
     u32 z0 = 0, z1 = 0, nd = 0;
@@ -864,6 +1013,17 @@ __global__ __launch_bounds__(ST_ML_THREADS) void strict_match_lds_kernel(
         const u64 dw = __ballot(isdirty);
         if ((tid & 63) == 0 && a0 + (tid & ~63) < n) dbits[(size_t)b * ((n + 63) / 64) + (a >> 6)] = dw;
         nd += isdirty;
+        if (lst) {
+            // the pair kernel's list: dirty curves (bit 31) and clean curves that cross the target; wave-aggregated append
+            const bool want = active && (!clean || (hf & 2));
+            const u64 wm = __ballot(want);
+            if (wm) {
+                u32 base = 0;
+                if ((tid & 63) == 0) base = atomicAdd(&lcount, (u32)__popcll(wm));
+                base = (u32)__builtin_amdgcn_readfirstlane((int)base);
+                if (want) lst[base + (u32)__popcll(wm & ((1ull << (tid & 63)) - 1ull))] = (u32)a | (isdirty ? 0x80000000u : 0u);
+            }
+        }
         if (active && clean) {
             if (!(hf & 2)) {                       // empty canonical mask: below throughout (side 0) / above throughout
                 z0 += side == 0;
@@ -969,6 +1129,12 @@ __global__ __launch_bounds__(ST_ML_THREADS) void strict_match_lds_kernel(
         for (int k = 0; k < ST_ML_THREADS / 64; ++k) { t0 += red[k][0]; t1 += red[k][1]; t2 += red[k][2]; }
         meta[b * 4] = (u32)t2;
         meta[b * 4 + 3] = overflow ? 1u : 0u;                 // the global-table kernels add this target's groups
+        if (ilist) {
+            u32 *hd = ilist + (size_t)b * (n + 4);
+            hd[0] = lcount;
+            hd[1] = (u32)(t1 >> 32);                          // z0: clean curves below the target throughout
+            hd[2] = (u32)t1;                                  // z1: ... above it throughout
+        }
         if (t2) dlist[atomicAdd(dcount, 1u)] = (u32)b;        // the pair kernel's work list
         // with whole_targets the pair kernel that follows counts ALL pairs of a target that has dirty curves
         if (!(whole_targets && t2)) out[(q0 + b) * jcols] = t0 + (t1 >> 32) * (t1 & 0xFFFFFFFFull);
@@ -1416,7 +1582,8 @@ static int launch_bd_strict_impl(const double *Y, i64 T, i64 n, const i64 *targe
     u64 *HF = (u64 *)cv.take((size_t)B * n * 8);                                    // hash + flags per (target, curve)
     unsigned char *dflag = (unsigned char *)cv.take((size_t)B * n);                 // dirty (target, curve) pairs
     u32 *dlist = (u32 *)cv.take((size_t)(B + 1) * 4);                               // dirty targets of the batch | their number
-    if (!masks || !xnan || !tab || !cmask || !Yt || !HF || !dflag || !dlist)
+    u32 *ilist = (u32 *)cv.take((size_t)B * (n + 4) * 4);                           // per target: the pair kernel's list of curves
+    if (!masks || !xnan || !tab || !cmask || !Yt || !HF || !dflag || !dlist || !ilist)
         return fail(SD_ERR_WORKSPACE, "strict-depth workspace too small");
     u32 *dcount = dlist + B;
     // cross-check builds, SD_STRICT_FP64_MASKS = 1: masks from the fp64 values at any n
@@ -1516,7 +1683,8 @@ static int launch_bd_strict_impl(const double *Y, i64 T, i64 n, const i64 *targe
                 SD_HIP(hipFuncSetAttribute((const void *)strict_match_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tb));
                 hipLaunchKernelGGL(strict_match_lds_kernel, dim3((unsigned)nb), dim3(ST_ML_THREADS), tb, s, (const u32 *)masks,
                                    (const u64 *)HF, T, n, targets, q0, xnan, (const u32 *)cmask, dirty, dbits, dlist, dcount,
-                                   (int)lslots, gen2 ? 0 : 1, force_global ? 1 : 0, out, jcols);
+                                   (int)lslots, gen2 ? 0 : 1, force_global ? 1 : 0, out, jcols,
+                                   (gen2 && xswitch("SD_STRICT_PAIRS2") != 1) ? ilist : (u32 *)nullptr);
                 if (global_possible) {
                     hipLaunchKernelGGL(strict_match_clear_kernel, dim3((unsigned)((slots + 4095) / 4096), (unsigned)nb), dim3(ST_THREADS),
                                        0, s, (const u32 *)dirty, keys, cnt, slots);
@@ -1549,8 +1717,13 @@ static int launch_bd_strict_impl(const double *Y, i64 T, i64 n, const i64 *targe
                     if (layers < ST_PAIR_LAYERS && per_layer <= 256) layers = ST_PAIR_LAYERS;
                     if (layers > nb) layers = nb;
                     dim3 g2m(g2.x, g2.y, (unsigned)layers);
-                    hipLaunchKernelGGL(strict_pairs2_kernel, g2m, dim3(ST_THREADS), 0, s, (const u32 *)masks, T, n, targets, q0, xnan,
-                                       (const u32 *)dlist, (const u32 *)dcount, (const u64 *)dbits, out, jcols);
+                    // cross-check builds, SD_STRICT_PAIRS2 = 1: every partner of a dirty curve through the mask test
+                    if (xswitch("SD_STRICT_PAIRS2") == 1)
+                        hipLaunchKernelGGL(strict_pairs2_kernel, g2m, dim3(ST_THREADS), 0, s, (const u32 *)masks, T, n, targets, q0, xnan,
+                                           (const u32 *)dlist, (const u32 *)dcount, (const u64 *)dbits, out, jcols);
+                    else
+                        hipLaunchKernelGGL(strict_pairs3_kernel, g2m, dim3(ST_THREADS), 0, s, (const u32 *)masks, T, n, q0,
+                                           (const u32 *)dlist, (const u32 *)dcount, (const u32 *)ilist, out, jcols);
                 } else {
                     hipLaunchKernelGGL(strict_pairs2_kernel, g2, dim3(ST_THREADS), 0, s, (const u32 *)masks, T, n, targets, q0, xnan,
                                        (const u32 *)nullptr, (const u32 *)nullptr, (const u64 *)nullptr, out, jcols);
