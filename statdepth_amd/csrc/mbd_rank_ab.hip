@@ -487,10 +487,14 @@ int launch_mbd_rank(const double *Y, i64 T, i64 n, const i64 *targets, i64 tbegi
         // the bucket kernel ranks every row itself: partial totals per workgroup, no pair image, no search launch
         u64 *partial = (u64 *)cv.take(mbd_rank_bucket_partial_bytes(n, J));
         if (!partial) return fail(SD_ERR_WORKSPACE, "rank workspace too small (bucket kernel)");
-        for (i64 row0 = 0; row0 < T; row0 += rpb) {
-            const i64 rows = T - row0 < rpb ? T - row0 : rpb;
+        // the two-launch path takes up to 4 096 rows per batch (its list of flagged rows sits in LDS): longer series go
+        // through it in batches of that size, the last one through whichever path takes its length
+        const bool two_level = J == 2 && !targets && tbegin == 0 && m == n;
+        const i64 step = (two_level && rpb > 4096 && rank_bucket_two_level_supported(n, 4096)) ? 4096 : rpb;
+        for (i64 row0 = 0; row0 < T; row0 += step) {
+            const i64 rows = T - row0 < step ? T - row0 : step;
             int rc, G = 0, p32 = 0;
-            if (J == 2 && !targets && tbegin == 0 && m == n && rank_bucket_two_level_supported(n, rows)) {
+            if (two_level && rank_bucket_two_level_supported(n, rows)) {
                 // 32-bit key images, two workgroups per CU; the second launch finalizes (and ranks what the first flagged)
                 if ((rc = launch_rank_bucket_two_level(Y, n, row0, rows, partial, out, row0 == 0, s))) return rc;
                 continue;
