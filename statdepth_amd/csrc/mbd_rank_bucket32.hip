@@ -382,18 +382,21 @@ __global__ __launch_bounds__(R32_NT, 4) void rank_bucket32_kernel(const double *
                     lt = __builtin_amdgcn_alignbit(lt, y1.z - qe, 31);
                     lt = __builtin_amdgcn_alignbit(lt, y1.w - qe, 31);
                     if (e + 1 < E) window(e + 1);
+                    u32 less = (u32)__popc(lt);
                     if (cnt + off > 8u) {                             // the rest of a long bucket (a few lanes per visit)
                         const uint4 *p = S4 + (base >> 2);
 #pragma unroll 1
-                        for (u32 kk = 8; kk < cnt + off; kk += 4) {
+                        for (u32 kk = 8; kk < cnt + off; kk += 4) {   // up to 63 + 3 positions: the bit list is counted per quad
                             const uint4 y = p[kk >> 2];
-                            lt = __builtin_amdgcn_alignbit(lt, y.x - qe, 31);
-                            lt = __builtin_amdgcn_alignbit(lt, y.y - qe, 31);
-                            lt = __builtin_amdgcn_alignbit(lt, y.z - qe, 31);
-                            lt = __builtin_amdgcn_alignbit(lt, y.w - qe, 31);
+                            u32 l4 = 0;
+                            l4 = __builtin_amdgcn_alignbit(l4, y.x - qe, 31);
+                            l4 = __builtin_amdgcn_alignbit(l4, y.y - qe, 31);
+                            l4 = __builtin_amdgcn_alignbit(l4, y.z - qe, 31);
+                            l4 = __builtin_amdgcn_alignbit(l4, y.w - qe, 31);
+                            less += (u32)__popc(l4);
                         }
                     }
-                    const u32 B = base - off + (u32)__popc(lt);       // keys with a smaller image
+                    const u32 B = base - off + less;                  // keys with a smaller image
                     kb[e] = B;
                     const bool isk = e < E - 2 || t + e * NT < n;
                     sB += isk ? B : 0u;
