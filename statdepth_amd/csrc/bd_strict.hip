@@ -732,31 +732,44 @@ __device__ __forceinline__ void strict_pairs2_target(const u32 *__restrict__ m32
 // below (never above) it -- DN_a (UN_a) empty -- so those partners, the bulk of banded or quantised data, are counted as
 // z0 (z1) per dirty curve without a look at their masks.  ilist[b]: {entries, z0, z1, -, entry...}; the a < c rule runs
 // on list positions.
+// Tiles of ST_P3_THREADS = 1 024 list positions, each walking the WHOLE list: a partner sub-chunk is staged once per 1 024 lanes
+// and a lane's own masks are fetched once per target (staging was half of the 256-thread, 512-partner form's time).
+constexpr int ST_P3_THREADS = 1024;
 __device__ __forceinline__ void strict_pairs3_target(const u32 *__restrict__ m32, i64 T, i64 n, i64 q0,
                                                      const u32 *__restrict__ ilist, u64 *__restrict__ out, int jcols,
-                                                     const i64 b) {
-    __shared__ u64 scratch[ST_THREADS / 64];
-    __shared__ u32 orparts[ST_THREADS / 64][2][ST_SUB];   // per wave: OR of its quarter of partner j's UN / DN words
+                                                     const i64 b, const int tile, const int chunk, const int chunks) {
+    __shared__ u64 scratch[ST_P3_THREADS / 64];
+    __shared__ u32 orparts[4][2][ST_SUB];   // per wave: OR of its quarter of partner j's UN / DN words
     __shared__ __attribute__((aligned(16))) u32 cm[ST_SUB][2 * ST_W32 + 4];   // partner j: UN words 0..31, DN words 0..31 (zero
                                                                                 // beyond W32); rows padded by 16 bytes: the survivors'
                                                                                 // per-lane rows fall on different banks
     __shared__ u32 sidx[ST_SUB];                            // the sub-chunk's curve indices (bit 31: dirty)
     const i64 q = q0 + b;
     const u32 *lst = ilist + (size_t)b * (n + 4);
-    const i64 len_l = (i64)lst[0];
+    const i64 nd_l = (i64)lst[0], nc_l = (i64)lst[3];          // dirty entries first, then the clean ones (stored from the back)
+    const i64 len_l = nd_l + nc_l;
     const u64 z0 = lst[1], z1 = lst[2];
     lst += 4;
-    const i64 apos = (i64)blockIdx.x * ST_THREADS + threadIdx.x;
-    const i64 b0 = (i64)blockIdx.y * ST_BCHUNK;
-    const i64 b1 = b0 + ST_BCHUNK < len_l ? b0 + ST_BCHUNK : len_l;
-    const i64 amin = (i64)blockIdx.x * ST_THREADS;
-    if (amin >= len_l) return;
-    const bool closed = blockIdx.y == 0;                   // this block also adds its lanes' pairs with the z0 / z1 curves
-    if (b1 - 1 <= amin && !closed) return;     // whole chunk at or below the tile: no a < b pair
+    auto entry = [&](i64 pos) -> u32 { return pos < nd_l ? lst[pos] : lst[n - 1 - (pos - nd_l)]; };
+    const i64 apos = (i64)tile * ST_P3_THREADS + threadIdx.x;
+    const i64 amin = (i64)tile * ST_P3_THREADS;
+    if (amin >= nd_l) return;                               // a tile without a dirty lane: every pair of its lanes with a dirty
+                                                            // curve is counted by that curve's lane (the earlier position)
+    // This block's share of the partners.  A tile with many dirty lanes walks the whole list itself (one staging per 1 024
+    // lanes, its masks fetched once); a few dirty lanes against a long list (a handful of ties in continuous data) are
+    // latency-bound on one block, so the list is cut into `chunks` pieces that run side by side.
+    const i64 dirty_here = nd_l - amin < ST_P3_THREADS ? nd_l - amin : ST_P3_THREADS;
+    const i64 nchunk = dirty_here >= 128 ? 1 : (i64)chunks;
+    const i64 csz = ((len_l + nchunk - 1) / nchunk + ST_SUB - 1) / ST_SUB * ST_SUB;
+    if ((i64)chunk >= nchunk) return;
+    const i64 b0 = (i64)chunk * csz;
+    const i64 b1 = b0 + csz < len_l ? b0 + csz : len_l;
+    const bool closed = chunk == 0;                   // this block also adds its lanes' pairs with the z0 / z1 curves
+    if ((b0 >= len_l || b1 - 1 <= amin) && !closed) return;   // no partner here, or the whole chunk at or below the tile
     const int W32 = (int)((T + 31) / 32);
     const u32 *mb = m32 + (size_t)b * 2 * W32 * n;
     const bool alive = apos < len_l;
-    const u32 ent = alive ? lst[apos] : 0u;
+    const u32 ent = alive ? entry(apos) : 0u;
     const i64 a = (i64)(ent & 0x7FFFFFFFu);
     u32 un[ST_W32], dn[ST_W32];
 #pragma unroll
@@ -778,11 +791,11 @@ __device__ __forceinline__ void strict_pairs3_target(const u32 *__restrict__ m32
         if (s0 + ST_SUB <= amin + 1) continue;                  // every partner of this sub-chunk at or below every lane's position
         const int len = (int)(b1 - s0 < ST_SUB ? b1 - s0 : ST_SUB);
         __syncthreads();                                        // the previous sub-chunk has been read
-        if (threadIdx.x < ST_SUB) sidx[threadIdx.x] = threadIdx.x < len ? lst[s0 + threadIdx.x] : 0u;
+        if (threadIdx.x < ST_SUB) sidx[threadIdx.x] = threadIdx.x < len ? entry(s0 + threadIdx.x) : 0u;
         __syncthreads();
         const u64 dsub = __ballot((int)(threadIdx.x & 63) < len && (sidx[threadIdx.x & 63] >> 31));   // dirty partners of this sub-chunk
         if (!tile_dirty && dsub == 0) continue;                 // clean tile x clean partners: counted by the matching
-        for (int e = threadIdx.x; e < ST_SUB * 2 * ST_W32; e += ST_THREADS) {
+        for (int e = threadIdx.x; e < ST_SUB * 2 * ST_W32; e += ST_P3_THREADS) {
             const int w2 = e / ST_SUB, j = e % ST_SUB;          // consecutive threads: consecutive partners of one word
             const int w = w2 % ST_W32;
             u32 v = 0;
@@ -791,7 +804,7 @@ __device__ __forceinline__ void strict_pairs3_target(const u32 *__restrict__ m32
         }
         __syncthreads();
         // which partners have an empty UN / DN mask: wave w ORs words 8w..8w+7 of partner j = lane, the four waves meet in LDS
-        {
+        if (threadIdx.x < 256) {
             const int j = threadIdx.x & 63, part = threadIdx.x >> 6;
             u32 pu = 0, pd = 0;
 #pragma unroll
@@ -875,15 +888,21 @@ __global__ __launch_bounds__(ST_THREADS) void strict_pairs2_kernel(
     }
 }
 
-// grid = (ceil(n / 256), ceil(n / ST_BCHUNK), layers): the targets of the matching's work list, each over its own list of
-// curves (blocks beyond a list's end leave at once)
-__global__ __launch_bounds__(ST_THREADS) void strict_pairs3_kernel(
+// A persistent 1-D grid over the items (dirty target of the matching's work list, tile of 1 024 list positions, chunk of
+// partners); an item without work (a tile beyond the target's dirty entries, a chunk the tile does not use) costs its block
+// a look at the list's header, not a workgroup launch: thousands of 1 024-thread workgroups that return at once cost more
+// in the dispatcher than the real ones cost in the kernel (measured: 3.3 -> 5.2 ms at 2 000 x 1 000 for twice the grid).
+__global__ __launch_bounds__(ST_P3_THREADS) void strict_pairs3_kernel(
     const u32 *__restrict__ m32, i64 T, i64 n, i64 q0, const u32 *__restrict__ dlist, const u32 *__restrict__ dcount,
-    const u32 *__restrict__ ilist, u64 *__restrict__ out, int jcols) {
-    const u32 cnt = *dcount;
-    for (u32 zi = blockIdx.z; zi < cnt; zi += gridDim.z) {
-        strict_pairs3_target(m32, T, n, q0, ilist, out, jcols, (i64)dlist[zi]);
-        __syncthreads();                           // the target's shared arrays are reused by the next one
+    const u32 *__restrict__ ilist, u64 *__restrict__ out, int jcols, int tiles, int chunks) {
+    const i64 cnt = (i64)*dcount, items = cnt * tiles * chunks;
+    // item = (chunk, tile, target), targets fastest: the items with work (chunk 0 of the first tiles of every target) are
+    // consecutive and spread evenly over the blocks
+    for (i64 it = blockIdx.x; it < items; it += gridDim.x) {
+        const i64 zi = it % cnt;
+        const int rem = (int)(it / cnt);
+        strict_pairs3_target(m32, T, n, q0, ilist, out, jcols, (i64)dlist[zi], rem % tiles, rem / tiles, chunks);
+        __syncthreads();                           // the item's shared arrays are reused by the next one
     }
 }
 
@@ -974,7 +993,7 @@ __global__ __launch_bounds__(ST_ML_THREADS) void strict_match_lds_kernel(
     u64 *__restrict__ out, int jcols, u32 *__restrict__ ilist) {
     extern __shared__ u32 tabl[];                             // keys [slots] | counters [slots]
     __shared__ u64 red[ST_ML_THREADS / 64][3];
-    __shared__ u32 lcount;                                    // entries of the pair kernel's curve list so far
+    __shared__ u32 lcount, ccount;                            // the pair kernel's curve list so far: dirty entries (from the front), clean ones (from the back)
     const i64 b = blockIdx.x;
     if (xnan[b]) return;
     const i64 tg = targets ? targets[q0 + b] : q0 + b;
@@ -986,7 +1005,7 @@ __global__ __launch_bounds__(ST_ML_THREADS) void strict_match_lds_kernel(
     u32 *cntl = tabl + slots;
     u32 *seen = cntl + slots;                                 // [2][ST_ML_SEEN / 32]: digests present on side 0 / side 1
     for (int e = tid; e < 2 * slots + 2 * (ST_ML_SEEN / 32); e += ST_ML_THREADS) tabl[e] = 0;
-    if (tid == 0) lcount = 0;
+    if (tid == 0) { lcount = 0; ccount = 0; }
     u32 *lst = ilist ? ilist + (size_t)b * (n + 4) + 4 : nullptr;
     __syncthreads();
     u64 acc = 0;
@@ -1014,14 +1033,21 @@ __global__ __launch_bounds__(ST_ML_THREADS) void strict_match_lds_kernel(
         if ((tid & 63) == 0 && a0 + (tid & ~63) < n) dbits[(size_t)b * ((n + 63) / 64) + (a >> 6)] = dw;
         nd += isdirty;
         if (lst) {
-            // the pair kernel's list: dirty curves (bit 31) and clean curves that cross the target; wave-aggregated append
-            const bool want = active && (!clean || (hf & 2));
-            const u64 wm = __ballot(want);
-            if (wm) {
+            // the pair kernel's list: dirty curves (bit 31) from the front, clean curves that cross the target from the back
+            // (n - 1 entries at most in all); wave-aggregated appends
+            const bool wantc = active && clean && (hf & 2);
+            const u64 wd = __ballot(isdirty), wc = __ballot(wantc);
+            if (wd) {
                 u32 base = 0;
-                if ((tid & 63) == 0) base = atomicAdd(&lcount, (u32)__popcll(wm));
+                if ((tid & 63) == 0) base = atomicAdd(&lcount, (u32)__popcll(wd));
                 base = (u32)__builtin_amdgcn_readfirstlane((int)base);
-                if (want) lst[base + (u32)__popcll(wm & ((1ull << (tid & 63)) - 1ull))] = (u32)a | (isdirty ? 0x80000000u : 0u);
+                if (isdirty) lst[base + (u32)__popcll(wd & ((1ull << (tid & 63)) - 1ull))] = (u32)a | 0x80000000u;
+            }
+            if (wc) {
+                u32 base = 0;
+                if ((tid & 63) == 0) base = atomicAdd(&ccount, (u32)__popcll(wc));
+                base = (u32)__builtin_amdgcn_readfirstlane((int)base);
+                if (wantc) lst[(u32)n - 1u - (base + (u32)__popcll(wc & ((1ull << (tid & 63)) - 1ull)))] = (u32)a;
             }
         }
         if (active && clean) {
@@ -1131,7 +1157,8 @@ __global__ __launch_bounds__(ST_ML_THREADS) void strict_match_lds_kernel(
         meta[b * 4 + 3] = overflow ? 1u : 0u;                 // the global-table kernels add this target's groups
         if (ilist) {
             u32 *hd = ilist + (size_t)b * (n + 4);
-            hd[0] = lcount;
+            hd[0] = lcount;                                   // dirty entries lst[0 .. hd[0]); clean ones lst[n - hd[3] .. n)
+            hd[3] = ccount;
             hd[1] = (u32)(t1 >> 32);                          // z0: clean curves below the target throughout
             hd[2] = (u32)t1;                                  // z1: ... above it throughout
         }
@@ -1722,8 +1749,14 @@ static int launch_bd_strict_impl(const double *Y, i64 T, i64 n, const i64 *targe
                         hipLaunchKernelGGL(strict_pairs2_kernel, g2m, dim3(ST_THREADS), 0, s, (const u32 *)masks, T, n, targets, q0, xnan,
                                            (const u32 *)dlist, (const u32 *)dcount, (const u64 *)dbits, out, jcols);
                     else
-                        hipLaunchKernelGGL(strict_pairs3_kernel, g2m, dim3(ST_THREADS), 0, s, (const u32 *)masks, T, n, q0,
-                                           (const u32 *)dlist, (const u32 *)dcount, (const u32 *)ilist, out, jcols);
+                    {
+                        const int tiles = (int)((n + ST_P3_THREADS - 1) / ST_P3_THREADS);
+                        const int chunks = n > 4096 ? 8 : (n > 1024 ? 4 : 1);
+                        i64 grid = (i64)nb * tiles * chunks;
+                        if (grid > 1024) grid = 1024;
+                        hipLaunchKernelGGL(strict_pairs3_kernel, dim3((unsigned)grid), dim3(ST_P3_THREADS), 0, s, (const u32 *)masks, T, n,
+                                           q0, (const u32 *)dlist, (const u32 *)dcount, (const u32 *)ilist, out, jcols, tiles, chunks);
+                    }
                 } else {
                     hipLaunchKernelGGL(strict_pairs2_kernel, g2, dim3(ST_THREADS), 0, s, (const u32 *)masks, T, n, targets, q0, xnan,
                                        (const u32 *)nullptr, (const u32 *)nullptr, (const u64 *)nullptr, out, jcols);

@@ -7,7 +7,9 @@ import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from statdepth_amd import engine
+from statdepth_amd import engine, _native
+if os.environ.get("SD_LIB"):                     # experiments: another build of the library (this tool only)
+    _native.LIB_PATH = os.path.abspath(os.environ["SD_LIB"])
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
 T = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
 kind = sys.argv[3] if len(sys.argv) > 3 else "walks"
