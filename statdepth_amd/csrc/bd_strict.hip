@@ -12,7 +12,7 @@
 // A NaN in the target fails everything (count 0).
 //
 // What runs, by case (launch_bd_strict_impl):
-//   J = 2, T <= 3, any n      strict_class_kernel: the masks ARE classes (4^T or 3^T of them); per target one pass over
+//   J = 2, T <= 5, any n      strict_class_kernel: the masks ARE classes (4^T or 3^T of them); per target one pass over
 //                             the curves and a class transform.  The L-infinity depth of point clouds.
 //   J = 2, n <= 131 071       per batch of targets: masks (strict_masks_rank_kernel from the bucket kernel's rank image
 //                             for n <= 32 767, else strict_masks2_kernel from the values) -> digests of the canonical
@@ -52,6 +52,12 @@ static inline i64 strict_table_slots(i64 n) {
     while (s < 2 * n) s <<= 1;
     return s;
 }
+// a series is "short" for the class kernel up to 5 timepoints: 81 / 243 counters per lane leave two to six waves per CU, and
+// still O(n) per target beats masks + matching at every size (10^5 x 4: 21 against 755 ms; 10^4 x 5: 1.3 against 2.7 ms)
+static inline bool strict_class_applies(i64 T, i64 n, int J) {
+    (void)n;
+    return J == 2 && T <= 5;
+}
 static inline bool strict_match_applies(i64 T, i64 n, int J) { return J == 2 && (T + 31) / 32 <= 65535 && n <= ST_MATCH_MAXN; }
 
 static i64 strict_batch(i64 T, i64 n, i64 m) {
@@ -84,11 +90,11 @@ static size_t strict_ws_for_batch(i64 T, i64 n, i64 b) {
 // bd_strict_min_workspace_bytes is the floor.
 size_t bd_strict_workspace_bytes(i64 T, i64 n, i64 m, int J) {
     // short series go through the class kernel (launch_bd_strict_classes): a flag, no images
-    if (J == 2 && T <= 3 && xswitch("SD_STRICT_V1") != 1 && xswitch("SD_STRICT_NOCLASS") != 1) return 4096;
+    if (strict_class_applies(T, n, J) && xswitch("SD_STRICT_V1") != 1 && xswitch("SD_STRICT_NOCLASS") != 1) return 4096;
     return strict_ws_for_batch(T, n, strict_batch(T, n, m));
 }
 size_t bd_strict_min_workspace_bytes(i64 T, i64 n, i64 m, int J) {
-    if (J == 2 && T <= 3 && xswitch("SD_STRICT_V1") != 1 && xswitch("SD_STRICT_NOCLASS") != 1) return 4096;
+    if (strict_class_applies(T, n, J) && xswitch("SD_STRICT_V1") != 1 && xswitch("SD_STRICT_NOCLASS") != 1) return 4096;
     return strict_ws_for_batch(T, n, 1);
 }
 // largest batch (<= the recommended one) whose layout fits ws_bytes; 0: not even one target fits
@@ -1416,6 +1422,11 @@ int launch_bd_strict_subsets(const double *Y, i64 T, i64 n, const int *members, 
 // between lanes); the points stream through the scalar cache, eight per load, the same for every lane of the block.
 // ---------------------------------------------------------------------------------------------------
 constexpr int ST_CL_THREADS = 128;
+// lanes (= targets) per block: the private histograms of a block must fit the LDS -- 3^T (NaN-free) or 4^T counters per lane
+__host__ __device__ constexpr int st_cl_threads(int TT, bool NANS) {
+    return TT <= 3 ? ST_CL_THREADS : (TT == 4 ? (NANS ? 64 : 128) : (NANS ? 32 : 64));
+}
+
 // is there a NaN anywhere in the data?  (flag[0] = 1)  NaN-free data -- the rule -- needs three states per coordinate
 // instead of four: 27 counters per lane instead of 64 at T = 3, and 2.4 x the waves per SIMD that hide this kernel's
 // LDS and scalar-load latencies.
@@ -1430,15 +1441,16 @@ __global__ __launch_bounds__(ST_THREADS) void strict_any_nan_kernel(const double
 }
 
 template <int TT, bool NANS>
-__global__ __launch_bounds__(ST_CL_THREADS) void strict_class_kernel(const double *__restrict__ Y, i64 n, const i64 *__restrict__ targets,
+__global__ __launch_bounds__(st_cl_threads(TT, NANS)) void strict_class_kernel(const double *__restrict__ Y, i64 n, const i64 *__restrict__ targets,
                                                                     const double *__restrict__ Q, i64 m, const u32 *__restrict__ nanflag,
                                                                     u64 *__restrict__ out, int jcols) {
     if ((nanflag[0] != 0) != NANS) return;                                   // the other instantiation serves this data
-    constexpr int P3 = TT == 1 ? 3 : (TT == 2 ? 9 : 27);
+    constexpr int P3 = TT == 1 ? 3 : (TT == 2 ? 9 : (TT == 3 ? 27 : (TT == 4 ? 81 : 243)));
     constexpr int NC = NANS ? (1 << (2 * TT)) : P3;
-    __shared__ u32 hist[NC][ST_CL_THREADS];
+    constexpr int CLT = st_cl_threads(TT, NANS);
+    __shared__ u32 hist[NC][CLT];
     const int tid = threadIdx.x;
-    const i64 q = (i64)blockIdx.x * ST_CL_THREADS + tid;
+    const i64 q = (i64)blockIdx.x * CLT + tid;
     const bool active = q < m;
     const i64 tg = (active && !Q) ? (targets ? targets[q] : q) : -1;        // its own column is not one of the others
     double x[TT];
@@ -1512,6 +1524,25 @@ __global__ __launch_bounds__(ST_CL_THREADS) void strict_class_kernel(const doubl
             const long long u = (long long)hist[c][tid];
             total += (__builtin_popcount((unsigned)c) & 1) ? -u * u : u * u;
         }
+    } else if constexpr (TT >= 4) {
+        // three states, 81 / 243 classes: too many for registers.  A pair is compatible iff in no coordinate both are above or
+        // both below: prod_t (1 - [both above at t] - [both below at t]) = sum over subsets S of the coordinates of (-1)^|S| [equal
+        // and strict on S].  In place, per coordinate, the tie slot becomes the sum of the three states (a wild card); entry c
+        // then counts the points that match c's strict digits, and the ordered pairs are sum_c (-1)^(strict digits of c) entry(c)^2.
+#pragma unroll 1
+        for (int stride = 1; stride < NC; stride *= 3)
+#pragma unroll 1
+            for (int g = 0; g < NC / 3; ++g) {
+                const int base = (g / stride) * stride * 3 + (g % stride);
+                hist[base][tid] += hist[base + stride][tid] + hist[base + 2 * stride][tid];
+            }
+#pragma unroll 1
+        for (int c = 0; c < NC; ++c) {
+            int strict_digits = 0;
+            for (int d = c; d; d /= 3) strict_digits += (d % 3) != 0;
+            const long long u = (long long)hist[c][tid];
+            total += (strict_digits & 1) ? -u * u : u * u;
+        }
     } else {
         // three states: z = (M x ... x M) h in registers (tie ~ all, above ~ {tie, below}, below ~ {tie, above}), then h . z
         u64 h[NC], z[NC];
@@ -1540,17 +1571,18 @@ int launch_bd_strict_classes(const double *Y, i64 T, i64 n, const i64 *targets, 
     if (!flag) return fail(SD_ERR_WORKSPACE, "strict-depth workspace too small");
     SD_HIP(hipMemsetAsync(flag, 0, 4, s));
     hipLaunchKernelGGL(strict_any_nan_kernel, dim3(1024), dim3(ST_THREADS), 0, s, Y, T * n, Q ? Q : Y, Q ? T * m : (i64)0, flag);
-    const unsigned grid = (unsigned)((m + ST_CL_THREADS - 1) / ST_CL_THREADS);
 #define ST_CL_LAUNCH(TT_)                                                                                                      \
-    hipLaunchKernelGGL((strict_class_kernel<TT_, false>), dim3(grid), dim3(ST_CL_THREADS), 0, s, Y, n, targets, Q, m,           \
-                       (const u32 *)flag, out, jcols);                                                                         \
-    hipLaunchKernelGGL((strict_class_kernel<TT_, true>), dim3(grid), dim3(ST_CL_THREADS), 0, s, Y, n, targets, Q, m,            \
-                       (const u32 *)flag, out, jcols);
+    hipLaunchKernelGGL((strict_class_kernel<TT_, false>), dim3((unsigned)((m + st_cl_threads(TT_, false) - 1) / st_cl_threads(TT_, false))), \
+                       dim3(st_cl_threads(TT_, false)), 0, s, Y, n, targets, Q, m, (const u32 *)flag, out, jcols);             \
+    hipLaunchKernelGGL((strict_class_kernel<TT_, true>), dim3((unsigned)((m + st_cl_threads(TT_, true) - 1) / st_cl_threads(TT_, true))),   \
+                       dim3(st_cl_threads(TT_, true)), 0, s, Y, n, targets, Q, m, (const u32 *)flag, out, jcols);
     switch ((int)T) {
         case 1: ST_CL_LAUNCH(1) break;
         case 2: ST_CL_LAUNCH(2) break;
         case 3: ST_CL_LAUNCH(3) break;
-        default: return fail(SD_ERR_UNSUPPORTED, "the class kernel covers up to three timepoints");
+        case 4: ST_CL_LAUNCH(4) break;
+        case 5: ST_CL_LAUNCH(5) break;
+        default: return fail(SD_ERR_UNSUPPORTED, "the class kernel covers up to five timepoints");
     }
 #undef ST_CL_LAUNCH
     SD_HIP(hipGetLastError());
@@ -1583,7 +1615,7 @@ int launch_bd_strict_external(const double *Y, i64 T, i64 n, const double *Q, i6
 static int launch_bd_strict_impl(const double *Y, i64 T, i64 n, const i64 *targets, const double *Q, i64 m, int J,
                                  u64 *out, void *ws, size_t ws_bytes, hipStream_t s) {
     // cross-check builds, SD_STRICT_NOCLASS = 1: short series through the mask kernels like any other
-    if (J == 2 && T <= 3 && xswitch("SD_STRICT_V1") != 1 && xswitch("SD_STRICT_NOCLASS") != 1)
+    if (strict_class_applies(T, n, J) && xswitch("SD_STRICT_V1") != 1 && xswitch("SD_STRICT_NOCLASS") != 1)
         return launch_bd_strict_classes(Y, T, n, Q ? nullptr : targets, Q, m, out, 1, ws, ws_bytes, s);
     i64 W = strict_words(T);
     const i64 B = strict_batch_for_ws(T, n, m, ws_bytes);     // the recommended batch, or what the caller's workspace holds
@@ -1599,7 +1631,7 @@ static int launch_bd_strict_impl(const double *Y, i64 T, i64 n, const i64 *targe
     // (m n^2 / 2 pair tests at ~2e11 per second) instead of starting it
     if (!match && J == 2 && (double)m * (double)n * (double)n * 0.5 > 2.0e14)
         return fail(SD_ERR_UNSUPPORTED, "strict band depth of %lld curves over %lld timepoints: pairs are counted by matching for up to "
-                    "%lld curves (any number for T <= 3); beyond that every pair is tested, %.1e tests here", (long long)n,
+                    "%lld curves (any number for T <= 5); beyond that every pair is tested, %.1e tests here", (long long)n,
                     (long long)T, (long long)ST_MATCH_MAXN, (double)m * (double)n * (double)n * 0.5);
     const i64 dwords = (n + 63) / 64;
     // keys | counters | per target {dirty, below, above, -} | dirty bitmaps
