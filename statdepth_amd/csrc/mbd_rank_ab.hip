@@ -405,6 +405,8 @@ int launch_rank_bucket(const double *Y, i64 n, i64 row0, i64 rows, int J, u64 *p
 int launch_rank_bucket_image(const double *Y, i64 n, i64 row0, i64 rows, u32 *AB, u32 *nnan, hipStream_t s);
 bool rank_bucket_two_level_supported(i64 n, i64 rows);
 int launch_rank_bucket_two_level(const double *Y, i64 n, i64 row0, i64 rows, u64 *partial, u64 *out, int first, hipStream_t s);
+u64 *rank_bucket_two_level_all_totals(u64 *partial, i64 n);
+int launch_rank_gather_totals(const u64 *all, const i64 *targets, i64 tbegin, i64 m, u64 *out, hipStream_t s);
 int launch_rank_finalize(const u64 *partial, int G, int p32, const u32 *AB, const u32 *nnan, const unsigned char *rowflag,
                          i64 rows, i64 n, const i64 *targets, i64 tbegin, i64 m, int J, u64 *out, int first,
                          hipStream_t s);
@@ -489,14 +491,21 @@ int launch_mbd_rank(const double *Y, i64 T, i64 n, const i64 *targets, i64 tbegi
         if (!partial) return fail(SD_ERR_WORKSPACE, "rank workspace too small (bucket kernel)");
         // the two-launch path takes up to 4 096 rows per batch (its list of flagged rows sits in LDS): longer series go
         // through it in batches of that size, the last one through whichever path takes its length
-        const bool two_level = J == 2 && !targets && tbegin == 0 && m == n;
-        const i64 step = (two_level && rpb > 4096 && rank_bucket_two_level_supported(n, 4096)) ? 4096 : rpb;
+        // (a call for a subset of the targets ranks every row all the same: the path computes the totals of ALL curves into
+        // the workspace and the subset is gathered at the end -- provided every batch of the call takes this path)
+        const bool all_targets = !targets && tbegin == 0 && m == n;
+        const i64 step = (J == 2 && rpb > 4096 && rank_bucket_two_level_supported(n, 4096)) ? 4096 : rpb;
+        bool every = J == 2;                                            // does every batch of this call take the two-launch path?
+        for (i64 row0 = 0; row0 < T && every; row0 += step) every = rank_bucket_two_level_supported(n, T - row0 < step ? T - row0 : step);
+        const bool subset_tl = !all_targets && every && m >= 1;
+        const bool two_level = J == 2 && (all_targets || subset_tl);
+        u64 *const tl_out = subset_tl ? rank_bucket_two_level_all_totals(partial, n) : out;
         for (i64 row0 = 0; row0 < T; row0 += step) {
             const i64 rows = T - row0 < step ? T - row0 : step;
             int rc, G = 0, p32 = 0;
             if (two_level && rank_bucket_two_level_supported(n, rows)) {
                 // 32-bit key images, two workgroups per CU; the second launch finalizes (and ranks what the first flagged)
-                if ((rc = launch_rank_bucket_two_level(Y, n, row0, rows, partial, out, row0 == 0, s))) return rc;
+                if ((rc = launch_rank_bucket_two_level(Y, n, row0, rows, partial, tl_out, row0 == 0, s))) return rc;
                 continue;
             }
             if ((rc = launch_rank_bucket(Y, n, row0, rows, J, partial, &p32, &G, s))) return rc;
@@ -504,6 +513,7 @@ int launch_mbd_rank(const double *Y, i64 T, i64 n, const i64 *targets, i64 tbegi
                                            row0 == 0, s)))
                 return rc;
         }
+        if (tl_out != out) return launch_rank_gather_totals(tl_out, targets, tbegin, m, out, s);
         return SD_OK;
     }
     u32 *AB = (u32 *)cv.take((size_t)rpb * n * 4);

@@ -1193,11 +1193,30 @@ u32 rank_bucket32_epoch();
 // J = 2, 4096 < n <= 11264, every curve a target: rank_bucket32_kernel (two workgroups per CU; zeroes out when `first`) + the
 // fp64 kernel's SEL form (sums the partial blocks into out; ranks the rows the first kernel flagged).  Two launches.  The
 // flags and the gate word sit behind the 2 * cus u32 partial blocks, inside the space sized for u64 blocks.
-bool rank_bucket_two_level_supported(i64 n, i64 rows) {
+// what the two-launch path carves out of the partial-block space: its u32 blocks, row flags, gate words, lists, the second
+// launch's blocks -- and, last, n u64 totals of ALL curves for calls that ask for a subset of the targets
+static size_t two_level_used_bytes(i64 n, i64 rows) {
     const size_t nst = (size_t)((n + 3) & ~3);
-    return rank_bucket32_supported(n, rows, rb_cus()) &&
-           (size_t)2 * rb_cus() * nst * 4 + (size_t)rows + 768 + rank_bucket32_list_bytes(2 * rb_cus()) + (size_t)rb_cus() * nst * 4 <=
-               (size_t)2 * rb_cus() * n * 8;
+    return (size_t)2 * rb_cus() * nst * 4 + align_up((size_t)rows, 64) + 64 + 256 + rank_bucket32_list_bytes(2 * rb_cus()) + 256 +
+           (size_t)rb_cus() * nst * 4 + 256;
+}
+bool rank_bucket_two_level_supported(i64 n, i64 rows) {
+    return rank_bucket32_supported(n, rows, rb_cus()) && two_level_used_bytes(n, rows) + (size_t)n * 8 <= (size_t)2 * rb_cus() * n * 8;
+}
+u64 *rank_bucket_two_level_all_totals(u64 *partial, i64 n) {        // sized for the largest batch (4 096 rows)
+    return reinterpret_cast<u64 *>(reinterpret_cast<char *>(partial) + align_up(two_level_used_bytes(n, 4096), 256));
+}
+
+// out[q] (=|+=) all[target q]: the subset of the totals a call asked for
+__global__ __launch_bounds__(256) void rank_gather_totals_kernel(const u64 *__restrict__ all, const i64 *__restrict__ targets, i64 tbegin,
+                                                                i64 m, u64 *__restrict__ out) {
+    const i64 q = (i64)blockIdx.x * 256 + threadIdx.x;
+    if (q < m) out[q] = all[targets ? targets[q] : tbegin + q];
+}
+int launch_rank_gather_totals(const u64 *all, const i64 *targets, i64 tbegin, i64 m, u64 *out, hipStream_t s) {
+    hipLaunchKernelGGL(rank_gather_totals_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s, all, targets, tbegin, m, out);
+    SD_HIP(hipGetLastError());
+    return SD_OK;
 }
 
 int launch_rank_bucket_two_level(const double *Y, i64 n, i64 row0, i64 rows, u64 *partial, u64 *out, int first, hipStream_t s) {
