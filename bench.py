@@ -99,8 +99,17 @@ def strict_roofline():
     return None
 
 
-def timed(fn, steps, warmup, stream, torch, barrier=None):
-    """(wall seconds, device ms per step) of `steps` calls of fn(i) behind `warmup` untimed ones."""
+def timed(fn, steps, warmup, stream, torch, barrier=None, clock_warm=0):
+    """(wall seconds, device ms per step) of `steps` calls of fn(i) behind `warmup` untimed ones.  clock_warm: further untimed
+    calls in front of those -- a GPU that has just been idle (a fresh process, a few microseconds of work per step) has not
+    reached its sustained clocks after 5 warm-up steps (measured: 0.0535 against 0.0518 ms per step over 20 timed steps);
+    reported in the line as clock_warmup_steps."""
+    for i in range(clock_warm):
+        fn(i)
+        if i % 100 == 99:
+            torch.cuda.synchronize()                       # keep the launch queue short: the timed region must not inherit a backlog
+    if clock_warm:
+        torch.cuda.synchronize()
     for i in range(warmup):
         fn(i)
     (barrier or torch.cuda.synchronize)()
@@ -520,7 +529,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    dt, dev_ms = timed(lambda i: step_on(i % K), args.steps, args.warmup, stream, torch, barrier)
+    clock_warm = max(0, 400 - args.warmup)                  # ~20 ms of the same step at N = 1
+    dt, dev_ms = timed(lambda i: step_on(i % K), args.steps, args.warmup, stream, torch, barrier, clock_warm)
     if use_dist:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -574,6 +584,7 @@ def main():
                                        (f"targets sharded x{N}, RCCL all-gather of curve blocks" if mode == "targets" else
                                         f"curves owned x{N}, timepoints sharded for the ranking: RCCL all-to-all + reduce-scatter"))},
             "pair_timepoints_per_s": value * T,
+            "clock_warmup_steps": clock_warm,
             "mode": {"used": mode, "cost_model_seconds": {"time": model["time"], "targets": model["targets"]},
                      "note": "statdepth_amd.distributed.mode_cost_model: exchange over one xGMI link per peer + the measured "
                              "single-GPU ranking rates; mode='auto' takes the cheaper decomposition"},
