@@ -264,8 +264,11 @@ def sharded_mbd_counts(X_loc, J=2, algo="auto", group=None, gather_result=False,
     rank = dist.get_rank(group)
     world = dist.get_world_size(group)
     if mode == "auto":
-        # every rank evaluates the same model on the same numbers (T, its block size, the world size): the same choice
-        mode = mode_cost_model(int(X_loc.shape[0]), int(X_loc.shape[1]), world, J, algo)["choice"]
+        # Every rank must take the same branch (the two modes run different collectives): the model sees only what all ranks
+        # share -- T, the world size and the LARGEST block (one small all-gather of the sizes, also the consistency check;
+        # skipped when the caller passes `sizes`) -- never this rank's own block size.
+        sizes = block_sizes(X_loc, group, sizes)
+        mode = mode_cost_model(int(X_loc.shape[0]), int(max(sizes)), world, J, algo)["choice"]
     if mode == "time":
         sizes = block_sizes(X_loc, group, sizes)
         local = sharded_mbd_counts_time(X_loc, J=J, algo=algo, group=group, sizes=sizes, _compute_all=_compute_all,
