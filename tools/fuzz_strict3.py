@@ -4,7 +4,7 @@ independent implementations -- the pair kernel that tests every partner of a dir
 kernel (SD_STRICT_FP64_MASKS, also the switch that takes n > 32 767 off the 32-bit rank image) and, on small cases, the first
 generation (SD_STRICT_V1: every pair tested).  Shapes: n from a few hundred to 45 000 (LDS table + small filter, table area as
 the filter above 13 107 curves, 32-bit ranks above 32 767), tie-heavy / banded / walks / integers, NaN, duplicated curves,
-constant timepoints.  usage: fuzz_strict3.py [cases] [seed]"""
+constant timepoints; short series (T <= 5: state classes against SD_STRICT_NOCLASS).  usage: fuzz_strict3.py [cases] [seed]"""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -32,8 +32,9 @@ def run(X, tg, **env):
 
 
 for c in range(cases):
-    cls = rng.choice(["small", "mid", "big", "huge"], p=[0.35, 0.3, 0.2, 0.15])
-    if cls == "small": n, T = int(rng.integers(50, 900)), int(rng.choice([33, 64, 100, 257, 1000]))
+    cls = rng.choice(["short", "small", "mid", "big", "huge"], p=[0.2, 0.25, 0.25, 0.15, 0.15])
+    if cls == "short": n, T = int(rng.choice([rng.integers(3, 400), rng.integers(400, 20000)])), int(rng.choice([1, 2, 3, 4, 5]))
+    elif cls == "small": n, T = int(rng.integers(50, 900)), int(rng.choice([33, 64, 100, 257, 1000]))
     elif cls == "mid": n, T = int(rng.integers(900, 6000)), int(rng.choice([40, 96, 130, 300]))
     elif cls == "big": n, T = int(rng.integers(13200, 30000)), int(rng.choice([33, 64, 70]))
     else: n, T = int(rng.integers(32800, 45000)), int(rng.choice([33, 40, 64]))
@@ -55,8 +56,11 @@ for c in range(cases):
     m = 48 if n > 6000 else min(n, 160)
     tg = np.sort(rng.choice(n, size=m, replace=False))
     a = run(X, tg)
-    refs = {"PAIRS2": run(X, tg, SD_STRICT_PAIRS2="1"), "FP64_MASKS": run(X, tg, SD_STRICT_FP64_MASKS="1")}
-    if n <= 900 and T <= 300:
+    if cls == "short":                                          # state classes against masks + matching
+        refs = {"NOCLASS": run(X, tg, SD_STRICT_NOCLASS="1")}
+    else:
+        refs = {"PAIRS2": run(X, tg, SD_STRICT_PAIRS2="1"), "FP64_MASKS": run(X, tg, SD_STRICT_FP64_MASKS="1")}
+    if n <= 900 and T <= 300 and cls != "short":
         refs["V1"] = run(X, tg, SD_STRICT_V1="1")
     for name, b in refs.items():
         if not (a == b).all():
