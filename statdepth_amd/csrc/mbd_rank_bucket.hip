@@ -221,28 +221,45 @@ __global__ __launch_bounds__(NT, (NT == 512 ? 4 : RB_WAVES_PER_EU(E))) void rank
             }
         }
         {   // (1b) the keys rank_bucket32_kernel set aside (equal 32-bit images): their rows are NaN-free and finite, a group
-            //      of equal images is complete in its workgroup's list, so B and A follow from the list and the doubles
+            //      of equal images is complete in its workgroup's list, so B and A follow from the list and the doubles.
+            //      Both lists of this workgroup at once, 64 lanes each: every lane fetches its own key's value (ONE round trip
+            //      to memory; a loop with a load per partner was a chain of them), the groups meet in LDS.
             constexpr int LCAP = 64, LW = 1 + 2 * LCAP;               // R32_LCAP, R32_LIST_WORDS (mbd_rank_bucket32.hip)
-            for (int w = blockIdx.x; w < Gsum; w += gridDim.x) {
-                const u32 *lb = listbuf + (size_t)w * LW;
-                const u32 L = lb[0];
-                if ((u32)t0 < L && L <= (u32)LCAP) {
-                    const u32 key = lb[1 + t0], be = lb[1 + LCAP + t0];
-                    const u32 c = key & 0x3FFFu;
-                    const double *rowp = Y + (row0 + (i64)w + (i64)(key >> 14) * Gsum) * n;
-                    const double xv = rowp[c];
+            double *xs = reinterpret_cast<double *>(Sm);              // [2][LCAP] values, then keys and (B0 | E0 << 16)
+            u32 *ks = reinterpret_cast<u32 *>(xs + 2 * LCAP), *bs_ = ks + 2 * LCAP;
+            const int k = t0 >> 6, i = t0 & 63;
+            for (int w0 = blockIdx.x; w0 < Gsum; w0 += 2 * (int)gridDim.x) {   // one trip: Gsum <= 2 gridDim on the host's grids
+                u32 L = 0, key = 0, be = 0;
+                double xv = 0.0;
+                if (t0 < 2 * LCAP) {
+                    const int w = w0 + k * (int)gridDim.x;
+                    if (w < Gsum) {
+                        const u32 *lb = listbuf + (size_t)w * LW;
+                        L = lb[0];
+                        if (L > (u32)LCAP) L = 0;
+                        if ((u32)i < L) {
+                            key = lb[1 + i];
+                            be = lb[1 + LCAP + i];
+                            xv = Y[(row0 + (i64)w + (i64)(key >> 14) * Gsum) * n + (key & 0x3FFFu)];
+                        }
+                    }
+                    xs[t0] = xv; ks[t0] = key; bs_[t0] = be;
+                }
+                __syncthreads();
+                if (t0 < 2 * LCAP && (u32)i < L) {
                     u32 B = be & 0xFFFFu, A = (u32)n - B - (be >> 16);
                     for (u32 j = 0; j < L; ++j) {
-                        const u32 kj = lb[1 + j];
-                        if (j != (u32)t0 && (kj >> 14) == (key >> 14) && (lb[1 + LCAP + j] & 0xFFFFu) == (be & 0xFFFFu)) {
-                            const double xj = rowp[kj & 0x3FFFu];
+                        const u32 kj = ks[k * LCAP + j];
+                        if (j != (u32)i && (kj >> 14) == (key >> 14) && (bs_[k * LCAP + j] & 0xFFFFu) == (be & 0xFFFFu)) {
+                            const double xj = xs[k * LCAP + j];
                             B += (xj < xv) ? 1u : 0u;
                             A += (xj > xv) ? 1u : 0u;
                         }
                     }
                     const u64 v = (u64)n - 1;
-                    atomicAdd(&out_tot[c], (v * (v - 1) - (u64)A * (A - 1) - (u64)B * (B - 1)) >> 1);
+                    atomicAdd(&out_tot[key & 0x3FFFu], (v * (v - 1) - (u64)A * (A - 1) - (u64)B * (B - 1)) >> 1);
                 }
+                __syncthreads();                                      // the next trip, and Sm is reused below
             }
         }
         if (*gate != epoch) return;                                   // (2) nothing was flagged
