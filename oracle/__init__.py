@@ -186,8 +186,6 @@ def bd_strict_counts_by_states(X, targets):
     tg = _targets(targets, n)
     out = np.zeros(len(tg), dtype=np.int64)
     NC = 1 << (2 * T)
-    cls = np.arange(NC)
-    compat = (cls[:, None] & cls[None, :]) == 0
     for k, q in enumerate(tg):
         x = X[:, q]
         if np.isnan(x).any():
@@ -198,8 +196,10 @@ def bd_strict_counts_by_states(X, targets):
             code |= ((X[t] > x[t]) | isn).astype(np.int64) << (2 * t)
             code |= ((X[t] < x[t]) | isn).astype(np.int64) << (2 * t + 1)
         code = np.delete(code, q)
-        h = np.bincount(code, minlength=NC).astype(object)          # Python integers: no overflow at n = 10^6
-        ordered = sum(int(h[c]) * int(h[compat[c]].sum()) for c in range(NC) if h[c])
+        h = np.bincount(code, minlength=NC)
+        used = np.flatnonzero(h)                                    # the classes that occur (4^T of them is 65 536 at T = 8)
+        hu = h[used].astype(object)                                 # Python integers: no overflow at n = 10^6
+        ordered = sum(int(hu[j]) * int(hu[(used & c) == 0].sum()) for j, c in enumerate(used))
         out[k] = (ordered - int(h[0])) // 2                         # class 0 (ties everywhere) is compatible with itself
     return out
 

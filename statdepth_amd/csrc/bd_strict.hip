@@ -12,6 +12,7 @@
 // A NaN in the target fails everything (count 0).
 //
 // What runs, by case (launch_bd_strict_impl):
+//   J = 2, 6 <= T <= 8, any n, NaN-free   strict_class_wg_kernel: the same classes counted by a workgroup per few targets
 //   J = 2, T <= 5, any n      strict_class_kernel: the masks ARE classes (4^T or 3^T of them); per target one pass over
 //                             the curves and a class transform.  The L-infinity depth of point clouds.
 //   J = 2, n <= 131 071       per batch of targets: masks (strict_masks_rank_kernel from the bucket kernel's rank image
@@ -58,6 +59,14 @@ static inline bool strict_class_applies(i64 T, i64 n, int J) {
     (void)n;
     return J == 2 && T <= 5;
 }
+// 6 ... 8 timepoints: 729 ... 6 561 three-state classes per target are too many for a histogram per lane; a workgroup takes a
+// few targets and counts into shared histograms (strict_class_wg_kernel).  NaN-free data only: four states would be 4^T
+// counters (256 KB at T = 8), so data with NaN goes the way it went before (masks + matching up to 131 071 curves).
+static inline bool strict_class_wg_applies(i64 T, int J) { return J == 2 && T >= 6 && T <= 8; }
+// ... and beyond the matching's reach, with more pairs than the pair kernel is allowed, they are the ONLY route
+static inline bool strict_class_wg_only(i64 T, i64 n, i64 m, int J) {
+    return strict_class_wg_applies(T, J) && n > 131071 && (double)m * (double)n * (double)n * 0.5 > 2.0e14;
+}
 static inline bool strict_match_applies(i64 T, i64 n, int J) { return J == 2 && (T + 31) / 32 <= 65535 && n <= ST_MATCH_MAXN; }
 
 static i64 strict_batch(i64 T, i64 n, i64 m) {
@@ -91,11 +100,15 @@ static size_t strict_ws_for_batch(i64 T, i64 n, i64 b) {
 size_t bd_strict_workspace_bytes(i64 T, i64 n, i64 m, int J) {
     // short series go through the class kernel (launch_bd_strict_classes): a flag, no images
     if (strict_class_applies(T, n, J) && xswitch("SD_STRICT_V1") != 1 && xswitch("SD_STRICT_NOCLASS") != 1) return 4096;
-    return strict_ws_for_batch(T, n, strict_batch(T, n, m));
+    // 6 ... 8 timepoints: the class kernel's flag in front of what the mask pipeline takes should the data hold NaN (beyond
+    // the matching's reach there is no such fallback: the flag only)
+    if (strict_class_wg_only(T, n, m, J)) return 4096;
+    return strict_ws_for_batch(T, n, strict_batch(T, n, m)) + (strict_class_wg_applies(T, J) ? 256 : 0);
 }
 size_t bd_strict_min_workspace_bytes(i64 T, i64 n, i64 m, int J) {
     if (strict_class_applies(T, n, J) && xswitch("SD_STRICT_V1") != 1 && xswitch("SD_STRICT_NOCLASS") != 1) return 4096;
-    return strict_ws_for_batch(T, n, 1);
+    if (strict_class_wg_only(T, n, m, J)) return 4096;
+    return strict_ws_for_batch(T, n, 1) + (strict_class_wg_applies(T, J) ? 256 : 0);
 }
 // largest batch (<= the recommended one) whose layout fits ws_bytes; 0: not even one target fits
 static i64 strict_batch_for_ws(i64 T, i64 n, i64 m, size_t ws_bytes) {
@@ -1589,6 +1602,134 @@ int launch_bd_strict_classes(const double *Y, i64 T, i64 n, const i64 *targets, 
     return SD_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// J = 2 over 6 ... 8 timepoints, NaN-free data, any n: the same state classes, counted by a WORKGROUP per G targets.
+// Lanes = points (their coordinates in VGPRs, SCW_PTS points per thread and trip, coalesced loads that serve all G targets);
+// the target's coordinates are wave-uniform (SGPRs), a pair costs 2 T compares, the base-3 code and one LDS atomic on the
+// target's histogram (3^T counters).  Then the in-place wild-card transform of strict_class_kernel, coordinate by
+// coordinate with the workgroup's threads, and sum_c (-1)^(strict digits of c) entry(c)^2.
+// ---------------------------------------------------------------------------------------------------
+constexpr int SCW_PTS = 4;
+template <int TT> struct ScwCfg {
+    static constexpr int NC = TT == 6 ? 729 : (TT == 7 ? 2187 : 6561);
+    static constexpr int G = TT == 6 ? 16 : (TT == 7 ? 8 : 4);          // 46 / 70 / 105 KB of histograms
+    static constexpr int NT = TT == 8 ? 1024 : 512;                     // three / two / one workgroup per CU
+    static constexpr size_t LDS = (size_t)G * NC * 4;
+};
+__device__ __forceinline__ double scw_uniform(double v) {               // a wave-uniform double into SGPRs
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    const u32 lo = (u32)__builtin_amdgcn_readfirstlane((int)(u32)b), hi = (u32)__builtin_amdgcn_readfirstlane((int)(u32)(b >> 32));
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
+template <int TT>
+__global__ __launch_bounds__(ScwCfg<TT>::NT) void strict_class_wg_kernel(const double *__restrict__ Y, i64 n,
+                                                                         const i64 *__restrict__ targets,
+                                                                         const double *__restrict__ Q, i64 m,
+                                                                         u64 *__restrict__ out, int jcols) {
+    using C = ScwCfg<TT>;
+    constexpr int NC = C::NC, G = C::G, NT = C::NT, NW = NT / 64;
+    extern __shared__ u32 scw_hist[];                                   // [G][NC]
+    __shared__ double xs[G][8];
+    __shared__ long long red[G][NW];
+    __shared__ u32 s_ties[G];
+    u32 *hist = scw_hist;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const i64 q0 = (i64)blockIdx.x * G;
+    const int gc = (int)(m - q0 < G ? m - q0 : G);                      // targets of this workgroup
+    for (int c = tid; c < G * NC; c += NT) hist[c] = 0;
+    if (tid < G * TT) {
+        const int g = tid / TT, t = tid % TT;
+        double v = 0.0;
+        if (g < gc) {
+            const i64 q = q0 + g;
+            v = Q ? Q[t * m + q] : Y[t * n + (targets ? targets[q] : q)];
+        }
+        xs[g][t] = v;
+    }
+    __syncthreads();
+    for (i64 i0 = tid; i0 < n; i0 += (i64)NT * SCW_PTS) {
+        double p[SCW_PTS][TT];
+        bool ok[SCW_PTS];
+#pragma unroll
+        for (int k = 0; k < SCW_PTS; ++k) {
+            const i64 i = i0 + (i64)k * NT;
+            ok[k] = i < n;
+#pragma unroll
+            for (int t = 0; t < TT; ++t) p[k][t] = ok[k] ? Y[t * n + i] : 0.0;
+        }
+#pragma unroll 1
+        for (int g = 0; g < gc; ++g) {
+            double x[TT];
+#pragma unroll
+            for (int t = 0; t < TT; ++t) x[t] = scw_uniform(xs[g][t]);
+            u32 *hg = hist + g * NC;
+#pragma unroll
+            for (int k = 0; k < SCW_PTS; ++k) {
+                u32 code = 0;
+#pragma unroll
+                for (int t = TT - 1; t >= 0; --t) code = code * 3u + (p[k][t] > x[t] ? 1u : 0u) + (p[k][t] < x[t] ? 2u : 0u);
+                if (ok[k]) atomicAdd(&hg[code], 1u);
+            }
+        }
+    }
+    __syncthreads();
+    // the target itself met in the stream as class 0 (every coordinate ties): taken off; class 0 = the points that tie with
+    // the target everywhere, the only ones compatible with themselves
+    if (tid < gc) {
+        const bool self = !Q && (targets ? targets[q0 + tid] : q0 + tid) >= 0;
+        if (self) hist[tid * NC] -= 1u;
+        s_ties[tid] = hist[tid * NC];
+    }
+    __syncthreads();
+    // per coordinate the tie slot becomes the sum of the three states (see strict_class_kernel)
+#pragma unroll 1
+    for (int stride = 1; stride < NC; stride *= 3) {
+        for (int w = tid; w < gc * (NC / 3); w += NT) {
+            const int g = w / (NC / 3), idx = w % (NC / 3);
+            u32 *h = hist + g * NC + (idx / stride) * stride * 3 + (idx % stride);
+            h[0] += h[stride] + h[2 * stride];
+        }
+        __syncthreads();
+    }
+    long long acc[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) acc[g] = 0;
+    for (int c = tid; c < NC; c += NT) {
+        int strict_digits = 0;
+#pragma unroll
+        for (int t = 0, d = c; t < TT; ++t, d /= 3) strict_digits += (d % 3) != 0;
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const long long u = (long long)hist[g * NC + c];
+            acc[g] += (strict_digits & 1) ? -u * u : u * u;
+        }
+    }
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        long long v = acc[g];
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+        if (lane == 0) red[g][wave] = v;
+    }
+    __syncthreads();
+    if (tid < gc) {
+        long long total = 0;
+        for (int w = 0; w < NW; ++w) total += red[tid][w];
+        out[(q0 + tid) * jcols] = ((u64)total - (u64)s_ties[tid]) / 2;
+    }
+}
+
+template <int TT>
+static int launch_class_wg(const double *Y, i64 n, const i64 *targets, const double *Q, i64 m, u64 *out, int jcols, hipStream_t s) {
+    using C = ScwCfg<TT>;
+    auto k = strict_class_wg_kernel<TT>;
+    SD_HIP(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS));
+    hipLaunchKernelGGL(k, dim3((unsigned)((m + C::G - 1) / C::G)), dim3(C::NT), C::LDS, s, Y, n, targets, Q, m, out, jcols);
+    SD_HIP(hipGetLastError());
+    return SD_OK;
+}
+
 // Q != nullptr: the m targets are EXTERNAL curves (T x m, time-major), every curve of Y is an "other" (J = 2 only).
 static int launch_bd_strict_impl(const double *Y, i64 T, i64 n, const i64 *targets, const double *Q, i64 m, int J,
                                  u64 *out, void *ws, size_t ws_bytes, hipStream_t s);
@@ -1617,6 +1758,32 @@ static int launch_bd_strict_impl(const double *Y, i64 T, i64 n, const i64 *targe
     // cross-check builds, SD_STRICT_NOCLASS = 1: short series through the mask kernels like any other
     if (strict_class_applies(T, n, J) && xswitch("SD_STRICT_V1") != 1 && xswitch("SD_STRICT_NOCLASS") != 1)
         return launch_bd_strict_classes(Y, T, n, Q ? nullptr : targets, Q, m, out, 1, ws, ws_bytes, s);
+    // 6 ... 8 timepoints: the workgroup form of the class kernel when no value is NaN.  That is a property of the data: the
+    // flag comes back to the host (one 4-byte copy and a wait on the stream -- the only route that waits), data with NaN goes
+    // on to the mask pipeline below
+    if (strict_class_wg_applies(T, J) && xswitch("SD_STRICT_V1") != 1 && xswitch("SD_STRICT_NOCLASS") != 1 && m > 0 && n > 0) {
+        if (!ws || ws_bytes < 256) return fail(SD_ERR_WORKSPACE, "strict-depth workspace too small");
+        u32 *flag = (u32 *)ws;
+        u32 hflag = 0;
+        SD_HIP(hipMemsetAsync(flag, 0, 4, s));
+        hipLaunchKernelGGL(strict_any_nan_kernel, dim3(1024), dim3(ST_THREADS), 0, s, Y, T * n, Q ? Q : Y, Q ? T * m : (i64)0, flag);
+        SD_HIP(hipMemcpyAsync(&hflag, flag, 4, hipMemcpyDeviceToHost, s));
+        SD_HIP(hipStreamSynchronize(s));
+        if (!hflag) {
+            const i64 *tg = Q ? nullptr : targets;
+            switch ((int)T) {
+                case 6: return launch_class_wg<6>(Y, n, tg, Q, m, out, 1, s);
+                case 7: return launch_class_wg<7>(Y, n, tg, Q, m, out, 1, s);
+                default: return launch_class_wg<8>(Y, n, tg, Q, m, out, 1, s);
+            }
+        }
+        if (strict_class_wg_only(T, n, m, J))
+            return fail(SD_ERR_UNSUPPORTED, "strict band depth of %lld curves over %lld timepoints with NaN in the data: the state "
+                        "classes of 6 to 8 timepoints take NaN-free data, matching takes up to %lld curves", (long long)n,
+                        (long long)T, (long long)ST_MATCH_MAXN);
+        ws = (char *)ws + 256;
+        ws_bytes -= 256;
+    }
     i64 W = strict_words(T);
     const i64 B = strict_batch_for_ws(T, n, m, ws_bytes);     // the recommended batch, or what the caller's workspace holds
     if (B < 1) return fail(SD_ERR_WORKSPACE, "strict-depth workspace too small: %zu bytes, one target takes %zu "
@@ -1631,7 +1798,7 @@ static int launch_bd_strict_impl(const double *Y, i64 T, i64 n, const i64 *targe
     // (m n^2 / 2 pair tests at ~2e11 per second) instead of starting it
     if (!match && J == 2 && (double)m * (double)n * (double)n * 0.5 > 2.0e14)
         return fail(SD_ERR_UNSUPPORTED, "strict band depth of %lld curves over %lld timepoints: pairs are counted by matching for up to "
-                    "%lld curves (any number for T <= 5); beyond that every pair is tested, %.1e tests here", (long long)n,
+                    "%lld curves (any number for T <= 5, and for T <= 8 without NaN); beyond that every pair is tested, %.1e tests here", (long long)n,
                     (long long)T, (long long)ST_MATCH_MAXN, (double)m * (double)n * (double)n * 0.5);
     const i64 dwords = (n + 63) / 64;
     // keys | counters | per target {dirty, below, above, -} | dirty bitmaps

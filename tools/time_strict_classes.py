@@ -1,11 +1,12 @@
-"""Strict depth of short series (T = 4, 5): the state-class kernel against masks + matching (SD_STRICT_NOCLASS, cross-check library)."""
+"""Strict depth of short series (T = 4 ... 8; argv: "n,T" pairs): the state-class kernel against masks + matching (SD_STRICT_NOCLASS, cross-check library)."""
 import os, sys, time, numpy as np
 sys.path.insert(0, ".")
 import torch
 torch.cuda.init()
 from statdepth_amd import engine, _native
 PRODUCT = _native.load(); XCHECK = _native.open_library(_native.XCHECK_LIB_PATH)
-for n, T in ((2000, 4), (10000, 4), (10000, 5), (100000, 4), (100000, 5), (30000, 5)):
+CASES = [tuple(int(v) for v in a.split(",")) for a in sys.argv[1:]] or [(2000, 4), (10000, 4), (10000, 5), (100000, 4), (100000, 5), (30000, 5)]
+for n, T in CASES:
     X = torch.from_numpy(np.random.default_rng(1).normal(size=(T, n))).cuda()
     res = []
     for force in (False, True):
