@@ -1577,6 +1577,10 @@ __global__ __launch_bounds__(st_cl_threads(TT, NANS)) void strict_class_kernel(c
     out[q * jcols] = tnan ? 0ull : ((u64)total - ties) / 2;                  // NaN in the target: nothing is contained
 }
 
+template <int TT>
+static int launch_class_wg(const double *Y, i64 n, const i64 *targets, const double *Q, i64 m, const u32 *nanflag, u64 *out, int jcols,
+                           hipStream_t s);
+
 int launch_bd_strict_classes(const double *Y, i64 T, i64 n, const i64 *targets, const double *Q, i64 m, u64 *out, int jcols,
                              void *ws, size_t ws_bytes, hipStream_t s) {
     Carver cv(ws, ws_bytes);
@@ -1593,8 +1597,27 @@ int launch_bd_strict_classes(const double *Y, i64 T, i64 n, const i64 *targets, 
         case 1: ST_CL_LAUNCH(1) break;
         case 2: ST_CL_LAUNCH(2) break;
         case 3: ST_CL_LAUNCH(3) break;
-        case 4: ST_CL_LAUNCH(4) break;
-        case 5: ST_CL_LAUNCH(5) break;
+        // T = 4, 5 without NaN: the workgroup form (lanes = points, shared histograms: 10^5 x 4 / 5 in 6.7 / 8.5 ms against 21 / 46
+        // with a histogram per lane); with NaN the four-state lane kernel.  Cross-check builds, SD_STRICT_LANECLASS = 1: the
+        // lane kernel for both.
+        case 4:
+        case 5:
+            if (xswitch("SD_STRICT_LANECLASS") == 1) {
+                if (T == 4) { ST_CL_LAUNCH(4) } else { ST_CL_LAUNCH(5) }
+                break;
+            }
+            if (T == 4) {
+                int rc = launch_class_wg<4>(Y, n, targets, Q, m, flag, out, jcols, s);
+                if (rc) return rc;
+                hipLaunchKernelGGL((strict_class_kernel<4, true>), dim3((unsigned)((m + st_cl_threads(4, true) - 1) / st_cl_threads(4, true))),
+                                   dim3(st_cl_threads(4, true)), 0, s, Y, n, targets, Q, m, (const u32 *)flag, out, jcols);
+            } else {
+                int rc = launch_class_wg<5>(Y, n, targets, Q, m, flag, out, jcols, s);
+                if (rc) return rc;
+                hipLaunchKernelGGL((strict_class_kernel<5, true>), dim3((unsigned)((m + st_cl_threads(5, true) - 1) / st_cl_threads(5, true))),
+                                   dim3(st_cl_threads(5, true)), 0, s, Y, n, targets, Q, m, (const u32 *)flag, out, jcols);
+            }
+            break;
         default: return fail(SD_ERR_UNSUPPORTED, "the class kernel covers up to five timepoints");
     }
 #undef ST_CL_LAUNCH
@@ -1611,10 +1634,13 @@ int launch_bd_strict_classes(const double *Y, i64 T, i64 n, const i64 *targets, 
 // ---------------------------------------------------------------------------------------------------
 constexpr int SCW_PTS = 4;
 template <int TT> struct ScwCfg {
-    static constexpr int NC = TT == 6 ? 729 : (TT == 7 ? 2187 : 6561);
-    static constexpr int G = TT == 6 ? 16 : (TT == 7 ? 8 : 4);          // 46 / 70 / 105 KB of histograms
+    static constexpr int NC = TT == 4 ? 81 : (TT == 5 ? 243 : (TT == 6 ? 729 : (TT == 7 ? 2187 : 6561)));
+    static constexpr int G = TT <= 6 ? 16 : (TT == 7 ? 8 : 4);          // (T >= 6:) 46 / 70 / 105 KB of histograms
     static constexpr int NT = TT == 8 ? 1024 : 512;                     // three / two / one workgroup per CU
-    static constexpr size_t LDS = (size_t)G * NC * 4;
+    // few classes: the lanes of a wave meet on the same counter (most points are strictly above or below in every coordinate:
+    // 2^T classes) and the LDS serialises them -- R copies of a target's histogram, a lane counts into copy lane % R
+    static constexpr int R = TT == 4 ? 8 : (TT == 5 ? 4 : 1);          // (16 / 8 copies with 8 targets: the same; 32: slower)
+    static constexpr size_t LDS = (size_t)G * R * NC * 4;
 };
 __device__ __forceinline__ double scw_uniform(double v) {               // a wave-uniform double into SGPRs
     const unsigned long long b = (unsigned long long)__double_as_longlong(v);
@@ -1626,10 +1652,12 @@ template <int TT>
 __global__ __launch_bounds__(ScwCfg<TT>::NT) void strict_class_wg_kernel(const double *__restrict__ Y, i64 n,
                                                                          const i64 *__restrict__ targets,
                                                                          const double *__restrict__ Q, i64 m,
+                                                                         const u32 *__restrict__ nanflag,
                                                                          u64 *__restrict__ out, int jcols) {
+    if (nanflag && nanflag[0] != 0) return;                             // (T <= 5: the four-state kernel serves this data)
     using C = ScwCfg<TT>;
-    constexpr int NC = C::NC, G = C::G, NT = C::NT, NW = NT / 64;
-    extern __shared__ u32 scw_hist[];                                   // [G][NC]
+    constexpr int NC = C::NC, G = C::G, NT = C::NT, NW = NT / 64, R = C::R, GS = R * NC;
+    extern __shared__ u32 scw_hist[];                                   // [G][R][NC]
     __shared__ double xs[G][8];
     __shared__ long long red[G][NW];
     __shared__ u32 s_ties[G];
@@ -1637,7 +1665,7 @@ __global__ __launch_bounds__(ScwCfg<TT>::NT) void strict_class_wg_kernel(const d
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const i64 q0 = (i64)blockIdx.x * G;
     const int gc = (int)(m - q0 < G ? m - q0 : G);                      // targets of this workgroup
-    for (int c = tid; c < G * NC; c += NT) hist[c] = 0;
+    for (int c = tid; c < G * GS; c += NT) hist[c] = 0;
     if (tid < G * TT) {
         const int g = tid / TT, t = tid % TT;
         double v = 0.0;
@@ -1663,7 +1691,7 @@ __global__ __launch_bounds__(ScwCfg<TT>::NT) void strict_class_wg_kernel(const d
             double x[TT];
 #pragma unroll
             for (int t = 0; t < TT; ++t) x[t] = scw_uniform(xs[g][t]);
-            u32 *hg = hist + g * NC;
+            u32 *hg = hist + g * GS + (lane & (R - 1)) * NC;
 #pragma unroll
             for (int k = 0; k < SCW_PTS; ++k) {
                 u32 code = 0;
@@ -1676,10 +1704,20 @@ __global__ __launch_bounds__(ScwCfg<TT>::NT) void strict_class_wg_kernel(const d
     __syncthreads();
     // the target itself met in the stream as class 0 (every coordinate ties): taken off; class 0 = the points that tie with
     // the target everywhere, the only ones compatible with themselves
+    if constexpr (R > 1) {
+        for (int w = tid; w < gc * NC; w += NT) {
+            u32 *h = hist + (w / NC) * GS + (w % NC);
+            u32 v = h[0];
+#pragma unroll
+            for (int r = 1; r < R; ++r) v += h[r * NC];
+            h[0] = v;
+        }
+        __syncthreads();
+    }
     if (tid < gc) {
         const bool self = !Q && (targets ? targets[q0 + tid] : q0 + tid) >= 0;
-        if (self) hist[tid * NC] -= 1u;
-        s_ties[tid] = hist[tid * NC];
+        if (self) hist[tid * GS] -= 1u;
+        s_ties[tid] = hist[tid * GS];
     }
     __syncthreads();
     // per coordinate the tie slot becomes the sum of the three states (see strict_class_kernel)
@@ -1687,7 +1725,7 @@ __global__ __launch_bounds__(ScwCfg<TT>::NT) void strict_class_wg_kernel(const d
     for (int stride = 1; stride < NC; stride *= 3) {
         for (int w = tid; w < gc * (NC / 3); w += NT) {
             const int g = w / (NC / 3), idx = w % (NC / 3);
-            u32 *h = hist + g * NC + (idx / stride) * stride * 3 + (idx % stride);
+            u32 *h = hist + g * GS + (idx / stride) * stride * 3 + (idx % stride);
             h[0] += h[stride] + h[2 * stride];
         }
         __syncthreads();
@@ -1701,7 +1739,7 @@ __global__ __launch_bounds__(ScwCfg<TT>::NT) void strict_class_wg_kernel(const d
         for (int t = 0, d = c; t < TT; ++t, d /= 3) strict_digits += (d % 3) != 0;
 #pragma unroll
         for (int g = 0; g < G; ++g) {
-            const long long u = (long long)hist[g * NC + c];
+            const long long u = (long long)hist[g * GS + c];
             acc[g] += (strict_digits & 1) ? -u * u : u * u;
         }
     }
@@ -1721,11 +1759,12 @@ __global__ __launch_bounds__(ScwCfg<TT>::NT) void strict_class_wg_kernel(const d
 }
 
 template <int TT>
-static int launch_class_wg(const double *Y, i64 n, const i64 *targets, const double *Q, i64 m, u64 *out, int jcols, hipStream_t s) {
+static int launch_class_wg(const double *Y, i64 n, const i64 *targets, const double *Q, i64 m, const u32 *nanflag, u64 *out, int jcols,
+                           hipStream_t s) {
     using C = ScwCfg<TT>;
     auto k = strict_class_wg_kernel<TT>;
     SD_HIP(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS));
-    hipLaunchKernelGGL(k, dim3((unsigned)((m + C::G - 1) / C::G)), dim3(C::NT), C::LDS, s, Y, n, targets, Q, m, out, jcols);
+    hipLaunchKernelGGL(k, dim3((unsigned)((m + C::G - 1) / C::G)), dim3(C::NT), C::LDS, s, Y, n, targets, Q, m, nanflag, out, jcols);
     SD_HIP(hipGetLastError());
     return SD_OK;
 }
@@ -1772,9 +1811,9 @@ static int launch_bd_strict_impl(const double *Y, i64 T, i64 n, const i64 *targe
         if (!hflag) {
             const i64 *tg = Q ? nullptr : targets;
             switch ((int)T) {
-                case 6: return launch_class_wg<6>(Y, n, tg, Q, m, out, 1, s);
-                case 7: return launch_class_wg<7>(Y, n, tg, Q, m, out, 1, s);
-                default: return launch_class_wg<8>(Y, n, tg, Q, m, out, 1, s);
+                case 6: return launch_class_wg<6>(Y, n, tg, Q, m, nullptr, out, 1, s);
+                case 7: return launch_class_wg<7>(Y, n, tg, Q, m, nullptr, out, 1, s);
+                default: return launch_class_wg<8>(Y, n, tg, Q, m, nullptr, out, 1, s);
             }
         }
         if (strict_class_wg_only(T, n, m, J))

@@ -4,6 +4,7 @@ sys.path.insert(0, ".")
 import torch
 torch.cuda.init()
 from statdepth_amd import engine, _native
+if os.environ.get("SD_LIB"): _native.LIB_PATH = os.path.abspath(os.environ["SD_LIB"])     # experiments: another build of the library
 PRODUCT = _native.load(); XCHECK = _native.open_library(_native.XCHECK_LIB_PATH)
 CASES = [tuple(int(v) for v in a.split(",")) for a in sys.argv[1:]] or [(2000, 4), (10000, 4), (10000, 5), (100000, 4), (100000, 5), (30000, 5)]
 for n, T in CASES:
