@@ -41,16 +41,36 @@ namespace sd {
 struct AB2 {
     u32 *B;
     u32 *A;
+    unsigned short *H;                         // half-word image (n <= AB2_H_MAXN, fold mode) or nullptr
 };
 constexpr u32 AB2_NAN = 0xFFFFFFFFu;           // B word: the curve is NaN at this timepoint
 constexpr u32 AB2_TIE = 0x80000000u;           // B word: A is in the second image
+// The fold wants C(v, j) - C(A, j) - C(B, j), symmetric in A and B, and an untied key has A + B = nreal - 1: min(A, B) says
+// it all and fits 16 bits up to 131 070 curves -- 2 bytes per (row, curve) written and read instead of 4 (config 3: 102 MB
+// less traffic).  AB2_H_WORD: look at the B word (NaN, or a tied key with its A in the second image).
+constexpr unsigned short AB2_H_WORD = 0xFFFFu;
+constexpr i64 AB2_H_MAXN = 131070;
 
+// an untied key: A = nreal - 1 - B
+__device__ __forceinline__ void ab_store_untied(const AB2 &ab, size_t idx, u32 B, u32 nreal) {
+    if (ab.H) {
+        const u32 A = nreal - 1u - B;
+        ab.H[idx] = (unsigned short)(A < B ? A : B);
+    } else {
+        ab.B[idx] = B;
+    }
+}
+__device__ __forceinline__ void ab_store_nan(const AB2 &ab, size_t idx) {
+    ab.B[idx] = AB2_NAN;
+    if (ab.H) ab.H[idx] = AB2_H_WORD;
+}
 __device__ __forceinline__ void ab_store(const AB2 &ab, size_t idx, u32 B, u32 A, u32 nreal) {
     if (A + B + 1u == nreal) {
-        ab.B[idx] = B;
+        ab_store_untied(ab, idx, B, nreal);
     } else {
         ab.B[idx] = B | AB2_TIE;
         ab.A[idx] = A;
+        if (ab.H) ab.H[idx] = AB2_H_WORD;
     }
 }
 
@@ -164,7 +184,7 @@ __global__ __launch_bounds__(BIG_NT) void chunk_search_kernel(const double *__re
                 if (x[e] == x[e])
                     ab_store(ab, dst + e * BIG_NT, lo[e], (x[e] == INF) ? 0u : (u32)(n - hi[e]) - nnan, (u32)n - nnan);
                 else
-                    ab.B[dst + e * BIG_NT] = AB2_NAN;
+                    ab_store_nan(ab, (size_t)(dst + e * BIG_NT));
             }
         }
     }
@@ -267,7 +287,7 @@ __global__ __launch_bounds__(1024) void bucket_partition_kernel(const double *__
                 off[e] = atomicAdd(&s_hist[lo], 1u);
             } else {
                 ++mynan;
-                ab.B[rb * n + i] = AB2_NAN;
+                ab_store_nan(ab, (size_t)(rb * n + i));
             }
         }
     }
@@ -347,7 +367,7 @@ __global__ __launch_bounds__(BP2_NT) void bucket_partition2_kernel(const double 
                 off[e] = atomicAdd(&s_hist[lo], 1u);
             } else {
                 ++mynan;
-                ab.B[rb * n + i] = AB2_NAN;
+                ab_store_nan(ab, (size_t)(rb * n + i));
             }
         }
     }
@@ -988,7 +1008,7 @@ __global__ __launch_bounds__(P3_NT) void bucket_partition3_kernel(const double *
                     }
                 } else {
                     ++mynan;
-                    ab.B[rb * n + i] = AB2_NAN;
+                    ab_store_nan(ab, (size_t)(rb * n + i));
                 }
             }
         }
@@ -1277,7 +1297,7 @@ __global__ __launch_bounds__(A3_NT) SD_A3_ATTR void bucket_rank32_kernel(const d
 #if defined(SD_TUNING) && defined(SD_A3_STOP)
                 if (SD_A3_STOP == 5) { if (gbase + base + less == 0xFFFFFFF0u) ab.B[abrow + id[e]] = 1; } else     // no store
 #endif
-                ab.B[abrow + id[e]] = gbase + base + less;            // untied: A = nreal - 1 - B
+                ab_store_untied(ab, abrow + id[e], gbase + base + less, nreal);
             } else {
                 // another member carries the same image: the fp64 values of those members decide
                 const double xv = yrow[id[e]];
@@ -1398,17 +1418,26 @@ __global__ __launch_bounds__(1024) void rank_accumulate2_kernel(AB2 ab, const u3
             const u32 A = (w & AB2_TIE) ? ab.A[row * n + i] : (u32)n - nn - 1u - B;     // tied keys carry their A
             band_counts_add<J>(A, B, nn, (u64)(n - 1), acc);
         };
+        // the word of (row, curve): from the half-word image where there is one (min(A, B) of an untied key stands for B:
+        // the counts are symmetric in A and B), else / on its marker from the B image
+        auto word = [&](i64 row) -> u32 {
+            if (ab.H) {
+                const u32 h = ab.H[row * n + i];
+                if (h != (u32)AB2_H_WORD) return h;
+            }
+            return ab.B[row * n + i];
+        };
         for (; r + 16 * 7 < rows; r += 16 * 8) {
             u32 w[8], nn[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                w[u] = ab.B[(r + 16 * u) * n + i];
+                w[u] = word(r + 16 * u);
                 nn[u] = nnan[r + 16 * u];
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) fold(w[u], nn[u], r + 16 * u);
         }
-        for (; r < rows; r += 16) fold(ab.B[r * n + i], nnan[r], r);
+        for (; r < rows; r += 16) fold(word(r), nnan[r], r);
     }
 #pragma unroll
     for (int j = 0; j < J - 1; ++j) {
@@ -1457,19 +1486,31 @@ __global__ __launch_bounds__(512) void rank_accumulate2x4_kernel(AB2 ab, const u
             }
         };
         const uint4 *img = reinterpret_cast<const uint4 *>(ab.B);
+        const uint2 *himg = reinterpret_cast<const uint2 *>(ab.H);
+        // four half words (8-byte loads) where there is a half-word image; a marker sends that curve to the B image
+        auto words = [&](i64 row) -> uint4 {
+            if (!himg) return img[(row * n + i0) >> 2];
+            const uint2 h = himg[(row * n + i0) >> 2];
+            uint4 w = make_uint4(h.x & 0xFFFFu, h.x >> 16, h.y & 0xFFFFu, h.y >> 16);
+            if (w.x == (u32)AB2_H_WORD) w.x = ab.B[row * n + i0];
+            if (w.y == (u32)AB2_H_WORD) w.y = ab.B[row * n + i0 + 1];
+            if (w.z == (u32)AB2_H_WORD) w.z = ab.B[row * n + i0 + 2];
+            if (w.w == (u32)AB2_H_WORD) w.w = ab.B[row * n + i0 + 3];
+            return w;
+        };
         i64 r = y;
         for (; r + 16 * 3 < rows; r += 16 * 4) {
             uint4 w[4];
             u32 nn[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                w[u] = img[((r + 16 * u) * n + i0) >> 2];
+                w[u] = words(r + 16 * u);
                 nn[u] = nnan[r + 16 * u];
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) fold4(w[u], nn[u], r + 16 * u);
         }
-        for (; r < rows; r += 16) fold4(img[(r * n + i0) >> 2], nnan[r], r);
+        for (; r < rows; r += 16) fold4(words(r), nnan[r], r);
     }
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
@@ -1489,6 +1530,100 @@ __global__ __launch_bounds__(512) void rank_accumulate2x4_kernel(AB2 ab, const u
     }
 }
 
+// The fold over the HALF-WORD image for a contiguous, 8-aligned block of targets: a thread takes EIGHT neighbouring curves
+// through 16-byte loads (16 lanes read 256 bytes of a row); block = 16 octets x 32 row slices.  A marker among the eight (NaN
+// / tied key: rare) sends that load through the B words.  Needs n % 8 == 0 and tbegin % 8 == 0.  J <= 3.
+template <int J>
+__global__ __launch_bounds__(512) void rank_accumulate_h8_kernel(AB2 ab, const u32 *__restrict__ nnan, i64 rows, i64 n,
+                                                                 i64 tbegin, i64 m, u64 *__restrict__ out, int first) {
+    __shared__ u64 red[32][16][9];                                    // (+1: the row slices fall on different banks)
+    const int x = threadIdx.x & 15, y = threadIdx.x >> 4;
+    const i64 q0 = ((i64)blockIdx.x * 16 + x) * 8;                    // first of this thread's eight targets
+    const i64 i0 = tbegin + q0;
+    u64 acc[8][JMAX - 1];
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+#pragma unroll
+        for (int j = 0; j < JMAX - 1; ++j) acc[c][j] = 0;
+    if (q0 < m) {
+        const uint4 *himg = reinterpret_cast<const uint4 *>(ab.H);
+        const u32 nm1 = (u32)n - 1u;
+        auto fold8 = [&](const uint4 v, u32 nn, i64 row) {
+            const u32 p[4] = {v.x, v.y, v.z, v.w};
+            u32 anym = 0;                                             // a half word 0xFFFF <=> a zero half word in ~p
+#pragma unroll
+            for (int k = 0; k < 4; ++k) anym |= ((~p[k]) - 0x00010001u) & p[k] & 0x80008000u;
+            if (J == 2 && nn == 0 && !anym) {
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    const u32 h = (c & 1) ? (p[c >> 1] >> 16) : (p[c >> 1] & 0xFFFFu);
+                    acc[c][0] += (u64)h * (u64)(nm1 - h);              // untied key of a NaN-free row: A * B
+                }
+                return;
+            }
+            // markers: the eight B words, and the eight A words when one of them is tied, through 16-byte loads as well (a
+            // tie-heavy row is markers throughout)
+            u32 bw[8] = {0, 0, 0, 0, 0, 0, 0, 0}, aw[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (anym) {
+                const uint4 *bp = reinterpret_cast<const uint4 *>(ab.B + row * n + i0);
+                const uint4 b0 = bp[0], b1 = bp[1];
+                bw[0] = b0.x; bw[1] = b0.y; bw[2] = b0.z; bw[3] = b0.w; bw[4] = b1.x; bw[5] = b1.y; bw[6] = b1.z; bw[7] = b1.w;
+                u32 anyt = 0;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    const u32 h = (c & 1) ? (p[c >> 1] >> 16) : (p[c >> 1] & 0xFFFFu);
+                    anyt |= (h == (u32)AB2_H_WORD && bw[c] != AB2_NAN) ? (bw[c] & AB2_TIE) : 0u;
+                }
+                if (anyt) {
+                    const uint4 *ap = reinterpret_cast<const uint4 *>(ab.A + row * n + i0);
+                    const uint4 a0 = ap[0], a1 = ap[1];
+                    aw[0] = a0.x; aw[1] = a0.y; aw[2] = a0.z; aw[3] = a0.w; aw[4] = a1.x; aw[5] = a1.y; aw[6] = a1.z; aw[7] = a1.w;
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                u32 w = (c & 1) ? (p[c >> 1] >> 16) : (p[c >> 1] & 0xFFFFu);
+                if (w == (u32)AB2_H_WORD) w = bw[c];
+                if (w == AB2_NAN) continue;
+                const u32 B = w & ~AB2_TIE;
+                const u32 A = (w & AB2_TIE) ? aw[c] : (u32)n - nn - 1u - B;
+                band_counts_add<J>(A, B, nn, (u64)(n - 1), acc[c]);
+            }
+        };
+        i64 r = y;
+        for (; r + 32 * 3 < rows; r += 32 * 4) {
+            uint4 w[4];
+            u32 nn[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                w[u] = himg[((r + 32 * u) * n + i0) >> 3];
+                nn[u] = nnan[r + 32 * u];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) fold8(w[u], nn[u], r + 32 * u);
+        }
+        for (; r < rows; r += 32) fold8(himg[(r * n + i0) >> 3], nnan[r], r);
+    }
+#pragma unroll
+    for (int j = 0; j < J - 1; ++j) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) red[y][x][c] = acc[c][j];
+        __syncthreads();
+        if (threadIdx.x < 128) {
+            const int xx = threadIdx.x >> 3, c = threadIdx.x & 7;
+            const i64 q = ((i64)blockIdx.x * 16 + xx) * 8 + c;
+            if (q < m) {
+                u64 tot = 0;
+#pragma unroll
+                for (int k = 0; k < 32; ++k) tot += red[k][xx][c];
+                if (first) out[q * (J - 1) + j] = tot;
+                else out[q * (J - 1) + j] += tot;
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // =====================================================================================================
 // host side
 // =====================================================================================================
@@ -1497,7 +1632,7 @@ static inline i64 big_nchunks(i64 n) { return (n + BIG_C - 1) / BIG_C; }
 struct BigPlan {
     i64 nch, sstride, rpb;
     int NB, NBT;                                         // interior value buckets; NBT = NB + 2 with the two end buckets
-    size_t off_ab, off_sorted, off_bval, off_bidx, off_spl, off_mk, off_tab, off_rp, off_zero, zero_bytes, total;
+    size_t off_ab, off_h, off_sorted, off_bval, off_bidx, off_spl, off_mk, off_tab, off_rp, off_zero, zero_bytes, total;
     // zeroed block: bcnt[rpb*NBT] | nnanrow[rpb] | ovf[rpb] | bflag[rpb*NBT] | nanrow_f[rpb] | rowtied[rpb]
     size_t z_bcnt, z_nnan, z_ovf, z_bflag, z_nanf, z_tied, z_gate;
 };
@@ -1520,6 +1655,7 @@ static BigPlan big_plan(i64 T, i64 n) {
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t at = o; o = align_up(o + bytes, 256); return at; };
     p.off_ab = take((size_t)r * n * 8);
+    p.off_h = take(n <= AB2_H_MAXN ? (size_t)r * n * 2 : 0);
     p.off_sorted = take((size_t)r * p.sstride * 8);
     p.off_bval = take((size_t)r * p.NBT * BK_C * 8);
     p.off_bidx = take((size_t)r * p.NBT * BK_C * 4);
@@ -1576,6 +1712,7 @@ static int big_run(const double *Y, i64 T, i64 n, const i64 *targets, i64 tbegin
     AB2 ab;                                                 // per batch: rpb * n words of B, then as many of A
     ab.B = (u32 *)(w + p.off_ab);
     ab.A = ab.B + (size_t)p.rpb * n;
+    ab.H = nullptr;
     double *sorted = (double *)(w + p.off_sorted);
     double *bval = (double *)(w + p.off_bval);
     u32 *bidx = (u32 *)(w + p.off_bidx);
@@ -1597,6 +1734,9 @@ static int big_run(const double *Y, i64 T, i64 n, const i64 *targets, i64 tbegin
 #else
     const bool gen2 = false;
 #endif
+    // fold mode up to 131 070 curves: the half-word image (cross-check builds, SD_BIG_NOHALF = 1: B words as before; the second
+    // generation's packed kernel writes B words only)
+    if (!img_out && !gen2 && n <= AB2_H_MAXN && xswitch("SD_BIG_NOHALF") != 1) ab.H = (unsigned short *)(w + p.off_h);
     const int NB = p.NB, NBT = p.NBT;
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) {
@@ -1720,7 +1860,11 @@ static int big_run(const double *Y, i64 T, i64 n, const i64 *targets, i64 tbegin
             continue;
         }
         const int first = row0 == 0;
-        if (!targets && (n & 3) == 0 && (tbegin & 3) == 0 && J <= 3) {
+        if (ab.H && !targets && (n & 7) == 0 && (tbegin & 7) == 0 && J <= 3) {
+            dim3 grid8((unsigned)((m + 127) / 128));
+            if (J == 2) hipLaunchKernelGGL((rank_accumulate_h8_kernel<2>), grid8, dim3(512), 0, s, ab, nn_for_fold, rows, n, tbegin, m, out, first);
+            else hipLaunchKernelGGL((rank_accumulate_h8_kernel<3>), grid8, dim3(512), 0, s, ab, nn_for_fold, rows, n, tbegin, m, out, first);
+        } else if (!targets && (n & 3) == 0 && (tbegin & 3) == 0 && J <= 3) {
             dim3 grid4((unsigned)((m + 127) / 128));
             if (J == 2) hipLaunchKernelGGL((rank_accumulate2x4_kernel<2>), grid4, dim3(512), 0, s, ab, nn_for_fold, rows, n, tbegin, m, out, first);
             else hipLaunchKernelGGL((rank_accumulate2x4_kernel<3>), grid4, dim3(512), 0, s, ab, nn_for_fold, rows, n, tbegin, m, out, first);
