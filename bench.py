@@ -227,6 +227,21 @@ def extras_single_gpu(torch, dev, stream, lib, check, ALGOS, oracle, reps=10):
     out["config5_linf_strict_1e6x3"] = {"workload": "L-infinity (box) depth, relax=False, 10^6 points in R^3, every point", "ms": ms,
                                         "point_pairs_per_s": float(n) * (n - 1) / (ms * 1e-3), "checked_targets": len(tg)}
     del Xd, res, ws
+    # the same depth in R^4 ... R^8 (10^5 points, every point a target): the workgroup form of the state-class kernel
+    for d in (4, 6, 8):
+        Xh = np.ascontiguousarray(np.random.default_rng(1237 + d).normal(size=(100000, d)).T)
+        Xd = torch.from_numpy(Xh).to(dev)
+        T, n = Xh.shape
+        res = torch.empty((n, 1), dtype=torch.int64, device=dev)
+        wsb = lib.sd_bd_strict_workspace_bytes(T, n, n, 1, n)
+        ws = torch.empty(int(wsb), dtype=torch.uint8, device=dev)
+        _, ms = timed(lambda _: check(lib.sd_bd_strict_counts(Xd.data_ptr(), T, n, n, 1, 0, n, res.data_ptr(), ws.data_ptr(), wsb,
+                                                             stream.cuda_stream)), 3, 1, stream, torch)
+        tg = np.array([0, 12345, 99999])
+        assert (res.cpu().numpy()[tg, 0] == oracle.bd_strict_counts_by_states(Xh, tg)).all(), f"strict linf 1e5 x {d}"
+        out[f"linf_strict_1e5x{d}"] = {"workload": f"L-infinity (box) depth, relax=False, 10^5 points in R^{d}, every point", "ms": ms,
+                                       "point_pairs_per_s": float(n) * (n - 1) / (ms * 1e-3), "checked_targets": len(tg)}
+        del Xd, res, ws
     # L1 depth and sampled simplicial depth
     P = np.random.default_rng(1237).normal(size=(100000, 3))
     Pd = torch.from_numpy(P).to(dev)

@@ -160,8 +160,10 @@ int sd_above_below(const double *X, int64_t T, int64_t n, int64_t st, int64_t sn
  * EVERY timepoint.  out[q] = number of such unordered pairs of other curves.
  * depth = out / C(n,2) on the host.
  * How the pairs are counted (always the same integers):
- *   T <= 3 (point clouds as `FunctionalDepth([points.T])`: the L-infinity / box depth), any n: per target one pass over
+ *   T <= 5 (point clouds as `FunctionalDepth([points.T])`: the L-infinity / box depth), any n: per target one pass over
  *     the curves into 3^T / 4^T state classes and a class transform -- O(n) per target;
+ *   T = 6 ... 8 without NaN anywhere, any n: the same (3^T classes; "NaN anywhere" is a flag the call reads back from the
+ *     device: for these T the call waits on `stream` once before it launches the counting).  With NaN: as below;
  *   n <= 131 071: curves that are strictly above or below the target at every timepoint ("clean") pair up exactly when
  *     their above-masks are complements, so those pairs are counted by grouping masks; pairs with a curve that ties
  *     with the target or holds NaN are tested one by one (only the targets that have such curves);
