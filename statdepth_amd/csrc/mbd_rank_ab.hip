@@ -556,7 +556,10 @@ int launch_rank_medium_image(const double *Y, i64 n, i64 row0, i64 rows, u32 *AB
 
 bool mbd_rank_medium_supported(i64 T, i64 n, int J) {
     // one workgroup per row: with few rows the large-n route, which spreads a row over several workgroups, fills the chip better
-    return rank_medium_supported(n) && T >= 96 && J >= 2 && J <= JMAX && xswitch("SD_BIG_NOMEDIUM") != 1;
+    // ... and since the large-n route's third generation (round 3) three column blocks lose to it: 40 960 x 500 in 0.322 against
+    // 0.287 ms, 32 768 (two blocks) 0.263 against 0.267.  Cross-check builds, SD_MEDIUM_WIDE = 1: up to the kernel's 40 960
+    const i64 top = xswitch("SD_MEDIUM_WIDE") == 1 ? (i64)40960 : (i64)32768;
+    return rank_medium_supported(n) && n <= top && T >= 96 && J >= 2 && J <= JMAX && xswitch("SD_BIG_NOMEDIUM") != 1;
 }
 
 size_t mbd_rank_medium_workspace_bytes(i64 T, i64 n, int J) {
@@ -567,7 +570,7 @@ size_t mbd_rank_medium_workspace_bytes(i64 T, i64 n, int J) {
 
 int launch_mbd_rank_medium(const double *Y, i64 T, i64 n, const i64 *targets, i64 tbegin, i64 m, int J, u64 *out, void *ws,
                            size_t ws_bytes, hipStream_t s) {
-    if (!mbd_rank_medium_supported(T, n, J)) return fail(SD_ERR_UNSUPPORTED, "medium rank route covers 16384 < n <= 40960 with T >= 96");
+    if (!mbd_rank_medium_supported(T, n, J)) return fail(SD_ERR_UNSUPPORTED, "medium rank route covers 16384 < n <= 32768 with T >= 96");
     const i64 rpb = ab_rows_per_batch(T, n);
     Carver cv(ws, ws_bytes);
     u32 *AB = (u32 *)cv.take((size_t)rpb * n * 4);

@@ -216,7 +216,7 @@ def sharded_mbd_counts_time(X_loc, J=2, algo="auto", group=None, sizes=None, _co
 
 # Measured single-GPU rates of the rank routes (keys ranked per second, MI355X) and of the pairwise
 # kernel (target x curve x timepoint triples per second); xGMI: one link per peer, ~50 GB/s per direction sustained.
-_RANK_KEYS_PER_S = ((16384, 2.1e11), (40960, 1.0e11), (1 << 62, 8.3e10))
+_RANK_KEYS_PER_S = ((16384, 2.1e11), (32768, 1.0e11), (1 << 62, 9.4e10))
 _PAIR_TRIPLES_PER_S = 8.3e12
 _LINK_BYTES_PER_S = 50e9
 
