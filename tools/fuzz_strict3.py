@@ -4,7 +4,7 @@ independent implementations -- the pair kernel that tests every partner of a dir
 kernel (SD_STRICT_FP64_MASKS, also the switch that takes n > 32 767 off the 32-bit rank image) and, on small cases, the first
 generation (SD_STRICT_V1: every pair tested).  Shapes: n from a few hundred to 45 000 (LDS table + small filter, table area as
 the filter above 13 107 curves, 32-bit ranks above 32 767), tie-heavy / banded / walks / integers, NaN, duplicated curves,
-constant timepoints; short series (T <= 5: state classes against SD_STRICT_NOCLASS).  usage: fuzz_strict3.py [cases] [seed]"""
+constant timepoints; short series (T <= 8: state classes -- lane and workgroup forms -- against SD_STRICT_NOCLASS).  usage: fuzz_strict3.py [cases] [seed]"""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -33,7 +33,7 @@ def run(X, tg, **env):
 
 for c in range(cases):
     cls = rng.choice(["short", "small", "mid", "big", "huge"], p=[0.2, 0.25, 0.25, 0.15, 0.15])
-    if cls == "short": n, T = int(rng.choice([rng.integers(3, 400), rng.integers(400, 20000)])), int(rng.choice([1, 2, 3, 4, 5]))
+    if cls == "short": n, T = int(rng.choice([rng.integers(3, 400), rng.integers(400, 20000)])), int(rng.choice([1, 2, 3, 4, 5, 6, 7, 8]))
     elif cls == "small": n, T = int(rng.integers(50, 900)), int(rng.choice([33, 64, 100, 257, 1000]))
     elif cls == "mid": n, T = int(rng.integers(900, 6000)), int(rng.choice([40, 96, 130, 300]))
     elif cls == "big": n, T = int(rng.integers(13200, 30000)), int(rng.choice([33, 64, 70]))
@@ -58,6 +58,7 @@ for c in range(cases):
     a = run(X, tg)
     if cls == "short":                                          # state classes against masks + matching
         refs = {"NOCLASS": run(X, tg, SD_STRICT_NOCLASS="1")}
+        if T in (4, 5): refs["LANECLASS"] = run(X, tg, SD_STRICT_LANECLASS="1")   # histogram per lane against the workgroup form
     else:
         refs = {"PAIRS2": run(X, tg, SD_STRICT_PAIRS2="1"), "FP64_MASKS": run(X, tg, SD_STRICT_FP64_MASKS="1")}
     if n <= 900 and T <= 300 and cls != "short":
