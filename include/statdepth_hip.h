@@ -163,7 +163,8 @@ int sd_above_below(const double *X, int64_t T, int64_t n, int64_t st, int64_t sn
  *   T <= 5 (point clouds as `FunctionalDepth([points.T])`: the L-infinity / box depth), any n: per target one pass over
  *     the curves into 3^T / 4^T state classes and a class transform -- O(n) per target;
  *   T = 6 ... 8 without NaN anywhere, any n: the same (3^T classes; "NaN anywhere" is a flag the call reads back from the
- *     device: for these T the call waits on `stream` once before it launches the counting).  With NaN: as below;
+ *     device: for these T the call waits on `stream` once before it launches the counting;
+ *     sd_bd_strict_nanfree_workspace_bytes is the workspace such data needs).  With NaN: as below;
  *   n <= 131 071: curves that are strictly above or below the target at every timepoint ("clean") pair up exactly when
  *     their above-masks are complements, so those pairs are counted by grouping masks; pairs with a curve that ties
  *     with the target or holds NaN are tested one by one (only the targets that have such curves);
@@ -175,6 +176,10 @@ int sd_above_below(const double *X, int64_t T, int64_t n, int64_t st, int64_t sn
  */
 size_t sd_bd_strict_workspace_bytes(int64_t T, int64_t n, int64_t st, int64_t sn, int64_t m);
 size_t sd_bd_strict_min_workspace_bytes(int64_t T, int64_t n, int64_t st, int64_t sn, int64_t m, int J);
+/* The size for a caller who knows that X holds no NaN (J = 2): a few KB for 6 ... 8 timepoints (the state classes need a flag,
+ * none of the mask pipeline's buffers), sd_bd_strict_workspace_bytes otherwise.  Passing it for data WITH NaN is safe: the
+ * call returns SD_ERR_WORKSPACE. */
+size_t sd_bd_strict_nanfree_workspace_bytes(int64_t T, int64_t n, int64_t st, int64_t sn, int64_t m);
 int sd_bd_strict_counts(const double *X, int64_t T, int64_t n, int64_t st, int64_t sn,
                         const int64_t *targets, int64_t m,
                         int64_t *out, void *ws, size_t ws_bytes, void *stream);

@@ -49,6 +49,7 @@ SIGNATURES = {
     "sd_bd_strict_external_counts": (_int, [_vp, _i64, _i64, _vp, _i64, _vp, _vp, _sz, _vp]),
     "sd_above_below": (_int, [_vp, _i64, _i64, _i64, _i64, _vp, _i64, _vp, _vp, _sz, _vp]),
     "sd_bd_strict_workspace_bytes": (_sz, [_i64, _i64, _i64, _i64, _i64]),
+    "sd_bd_strict_nanfree_workspace_bytes": (_sz, [_i64, _i64, _i64, _i64, _i64]),
     "sd_bd_strict_min_workspace_bytes": (_sz, [_i64, _i64, _i64, _i64, _i64, _int]),
     "sd_bd_strict_counts": (_int, [_vp, _i64, _i64, _i64, _i64, _vp, _i64, _vp, _vp, _sz, _vp]),
     "sd_bd_strict_j_workspace_bytes": (_sz, [_i64, _i64, _i64, _i64, _i64, _int]),

@@ -105,6 +105,11 @@ size_t bd_strict_workspace_bytes(i64 T, i64 n, i64 m, int J) {
     if (strict_class_wg_only(T, n, m, J)) return 4096;
     return strict_ws_for_batch(T, n, strict_batch(T, n, m)) + (strict_class_wg_applies(T, J) ? 256 : 0);
 }
+// what a caller who KNOWS the data NaN-free needs: the flag alone where the state classes of 6 ... 8 timepoints take such data
+size_t bd_strict_nanfree_workspace_bytes(i64 T, i64 n, i64 m, int J) {
+    if (strict_class_wg_applies(T, J) && xswitch("SD_STRICT_V1") != 1 && xswitch("SD_STRICT_NOCLASS") != 1) return 4096;
+    return bd_strict_workspace_bytes(T, n, m, J);
+}
 size_t bd_strict_min_workspace_bytes(i64 T, i64 n, i64 m, int J) {
     if (strict_class_applies(T, n, J) && xswitch("SD_STRICT_V1") != 1 && xswitch("SD_STRICT_NOCLASS") != 1) return 4096;
     if (strict_class_wg_only(T, n, m, J)) return 4096;

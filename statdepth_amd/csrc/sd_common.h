@@ -90,6 +90,7 @@ int launch_mbd_rank_big(const double *Y, i64 T, i64 n, const i64 *targets, i64 t
 // K3 strict
 size_t bd_strict_workspace_bytes(i64 T, i64 n, i64 m, int J);
 size_t bd_strict_min_workspace_bytes(i64 T, i64 n, i64 m, int J);
+size_t bd_strict_nanfree_workspace_bytes(i64 T, i64 n, i64 m, int J);
 int launch_bd_strict(const double *Y, i64 T, i64 n, const i64 *targets, i64 m, int J,
                      u64 *out, void *ws, size_t ws_bytes, hipStream_t s);
 size_t bd_strict_external_workspace_bytes(i64 T, i64 n, i64 m);
