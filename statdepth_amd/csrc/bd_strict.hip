@@ -1640,11 +1640,14 @@ int launch_bd_strict_classes(const double *Y, i64 T, i64 n, const i64 *targets, 
 constexpr int SCW_PTS = 4;
 template <int TT> struct ScwCfg {
     static constexpr int NC = TT == 4 ? 81 : (TT == 5 ? 243 : (TT == 6 ? 729 : (TT == 7 ? 2187 : 6561)));
-    static constexpr int G = TT <= 6 ? 16 : (TT == 7 ? 8 : 4);          // (T >= 6:) 46 / 70 / 105 KB of histograms
+    static constexpr int G = TT <= 5 ? 16 : (TT <= 7 ? 8 : 4);          // (T >= 6:) 46 / 70 / 105 KB of histograms
     static constexpr int NT = TT == 8 ? 1024 : 512;                     // three / two / one workgroup per CU
     // few classes: the lanes of a wave meet on the same counter (most points are strictly above or below in every coordinate:
     // 2^T classes) and the LDS serialises them -- R copies of a target's histogram, a lane counts into copy lane % R
-    static constexpr int R = TT == 4 ? 8 : (TT == 5 ? 4 : 1);          // (16 / 8 copies with 8 targets: the same; 32: slower)
+    // T = 6: 8 targets x 2 copies against 16 x 1: 10.1 against 15.6 ms on random walks (correlated coordinates: fewer classes
+    // occur), the same on independent ones; T = 7 / 8 with copies (4 x 2 / 2 x 2 targets): 13.2 / 23.3 against 15.1 / 20.0 on walks,
+    // 13.1 / 23.4 against 12.2 / 18.5 on independent coordinates -- not taken
+    static constexpr int R = TT == 4 ? 8 : (TT == 5 ? 4 : (TT == 6 ? 2 : 1));
     static constexpr size_t LDS = (size_t)G * R * NC * 4;
 };
 __device__ __forceinline__ double scw_uniform(double v) {               // a wave-uniform double into SGPRs
