@@ -882,7 +882,20 @@ __global__ __launch_bounds__(SNT) void bucket_setup_kernel(const double *__restr
         if (j >= 1) {                                                   // interior bucket j = (s_{j-1}, s_j]
             const int pp = (j - 1 == 0) ? 0 : (int)(((i64)(j - 1) * SS) / NB);
             const double sp = Sm[r2_phys<LE>(pp)] + 0.0;
-            mk[rb * NBT + j] = (double)Q_MAX / (sj - sp);
+            double m = (double)Q_MAX / (sj - sp);
+            // The outermost interior buckets reach from the first / last quantile splitter to the sample's extreme: under heavy
+            // tails nearly all of their keys sit at the inner end and a linear image crowds them into a few of A3's fine buckets
+            // (Cauchy rows: 81 keys in the first, above its 63 -- the value bucket went to the search kernel, 120 us at config
+            // 3's size).  Where the sample's median inside such a bucket lies in the inner eighth of its range the bucket takes
+            // the float-like code of the distance to its inner splitter, like the end buckets beyond it (mk = 0 says so).
+            if (j == 1 && NS >= 3) {
+                const double med = Sm[r2_phys<LE>(pos / 2)];
+                if ((sj - med) * 8.0 < (sj - sp)) m = 0.0;
+            } else if (j == NS - 1 && NS >= 3) {
+                const double med = Sm[r2_phys<LE>((pp + pos) / 2)];
+                if ((med - sp) * 8.0 < (sj - sp)) m = 0.0;
+            }
+            mk[rb * NBT + j] = m;
         }
     }
     if (t == 0) {
@@ -993,11 +1006,11 @@ __global__ __launch_bounds__(P3_NT) void bucket_partition3_kernel(const double *
                     if (!tied) {
                         const double xc = xv + 0.0;
                         u32 qq;
-                        if (a == 0) {
-                            const u32 cd = q_code(q_ord(s_spl[0]) - q_ord(xc));
+                        if (s_mk[a] == 0.0 && a <= 1) {                 // below the sample / a skewed first interior bucket (S3)
+                            const u32 cd = q_code(q_ord(s_spl[a]) - q_ord(xc));
                             qq = Q_MAX - (cd < Q_MAX ? cd : Q_MAX);
-                        } else if (a == NS) {
-                            const u32 cd = q_code(q_ord(xc) - q_ord(s_spl[NS - 1]));
+                        } else if (s_mk[a] == 0.0) {                    // above the sample / a skewed last interior bucket / no width
+                            const u32 cd = q_code(q_ord(xc) - q_ord(s_spl[a - 1]));
                             qq = cd < Q_MAX ? cd : Q_MAX;
                         } else {
                             double v = (xc - s_spl[a - 1]) * s_mk[a];

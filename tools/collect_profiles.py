@@ -9,6 +9,7 @@
 
 usage: collect_profiles.py <tag> [workload ...]       e.g. r03 (everything) or r03b config3 (stats + traffic of one)
 """
+import shutil
 import csv
 import glob
 import json
@@ -39,6 +40,7 @@ WORKLOADS = {
 
 
 def run(cmd, d):
+    shutil.rmtree(d, ignore_errors=True)             # an earlier run's files under the same tag would be picked up below
     r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
     print(" ".join(cmd[:6]), "... rc", r.returncode, flush=True)
     if r.returncode:
