@@ -31,7 +31,8 @@ sys.path.insert(0, ROOT)
 HBM_PEAK = 8.0e12          # B/s, MI355X spec (MI355X_MICROARCH.md)
 # lane-instructions/s: 256 CUs x 4 SIMD-32 x 32 lanes x 2.4 GHz -- a wave64 instruction issues over 2 cycles when its SIMD has
 # several waves to pick from (MI355X_MICROARCH.md, "Each CU has 4 SIMD-32 units"; one wave alone: 4).  Rounds 1-2 priced against
-# 16 lanes (4 cycles): half of this, and strict_class_wg_kernel<4> measures above that figure (profiles/r03l_issue_roofline.json)
+# 16 lanes (4 cycles): half of this.  Measured per instruction (profiles/r03m_valu_rate.txt): two-operand integer / fp32 reach it,
+# three-operand, compare, carry and fp64 instructions take 4.1 cycles -- a kernel made of those saturates at frac ~ 0.5
 VALU_PEAK = 256 * 4 * 32 * 2.4e9
 
 

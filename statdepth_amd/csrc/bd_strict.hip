@@ -407,6 +407,15 @@ __global__ __launch_bounds__(ST_THREADS) void strict_masks_rank_kernel(
     // waiting on that scalar load for half of its cycles (SQ_WAIT_INST_ANY 0.55 of the wave cycles).
     typedef u32 u32x16 __attribute__((ext_vector_type(16)));
     const u32 H = 0x80008000u;
+    // Round 3, after the instruction costs were measured (tools/experiments/valu_rate.hip): v_alignbit_b32 and v_bfi_b32 issue in
+    // 4.1 cycles each, v_and_b32 / v_lshrrev_b32 / v_or_b32 in 2.0 - 2.1.  The accumulator starts at 0 and each half is a 16-bit
+    // shift register that is full after exactly 16 steps, so a plain 32-bit shift never carries a set bit from the upper half
+    // into bit 15: shift, mask, or -- three two-cycle instructions (6.2 cycles) instead of rotate + insert (8.2).
+#ifdef SD_MASK_ROTATE_BFI
+#define ST_SHIFT_IN(acc, d) asm("v_alignbit_b32 %0, %0, %0, 1\n\tv_bfi_b32 %0, %2, %1, %0" : "+v"(acc) : "v"(d), "s"(H))
+#else
+#define ST_SHIFT_IN(acc, d) asm("v_lshrrev_b32 %0, 1, %0\n\tv_and_b32 %1, %2, %1\n\tv_or_b32 %0, %0, %1" : "+v"(acc), "+v"(d) : "s"(H))
+#endif
     i64 b = o.dlist ? (i64)o.dlist[z0] : z0;
     u32x16 qv = *reinterpret_cast<const u32x16 *>(Rt + (b * W32 + k) * 16);
     for (i64 z = z0; z < zend; ++z) {
@@ -416,8 +425,8 @@ __global__ __launch_bounds__(ST_THREADS) void strict_masks_rank_kernel(
         if (no_ties) {                                                  // block-uniform
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
-                const u32 d1 = qv[j] - xm[j];                           // (q + 0x8000) - x per half; bit 15 / 31: x <= q
-                asm("v_alignbit_b32 %0, %0, %0, 1\n\tv_bfi_b32 %0, %2, %1, %0" : "+v"(na) : "v"(d1), "s"(H));
+                u32 d1 = qv[j] - xm[j];                                 // (q + 0x8000) - x per half; bit 15 / 31: x <= q
+                ST_SHIFT_IN(na, d1);
             }
             if (i < n) {
                 o.m32[((size_t)b * 2 * W32 + k) * n + i] = ~na | nanbits;
@@ -429,8 +438,8 @@ __global__ __launch_bounds__(ST_THREADS) void strict_masks_rank_kernel(
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
                 const u32 q2 = qv[j];
-                const u32 d1 = q2 - xm[j];                              // (q + 0x8000) - x per half; bit 15 / 31: x <= q
-                asm("v_alignbit_b32 %0, %0, %0, 1\n\tv_bfi_b32 %0, %2, %1, %0" : "+v"(na) : "v"(d1), "s"(H));
+                u32 d1 = q2 - xm[j];                                    // (q + 0x8000) - x per half; bit 15 / 31: x <= q
+                ST_SHIFT_IN(na, d1);
                 const u32 e = (xh[j] ^ H) ^ q2;                         // x2 ^ q2 (xh = x2 | H)
                 mn = __builtin_elementwise_min(mn, __builtin_bit_cast(u16x2, e));
             }
@@ -443,12 +452,12 @@ __global__ __launch_bounds__(ST_THREADS) void strict_masks_rank_kernel(
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
                 const u32 q2 = qv[j];
-                const u32 d1 = q2 - xm[j];                              // (q + 0x8000) - x per half; bit 15 / 31: x <= q
-                const u32 d2 = xh[j] - q2;                              // (x + 0x8000) - q per half; bit 15 / 31: x >= q
+                u32 d1 = q2 - xm[j];                                    // (q + 0x8000) - x per half; bit 15 / 31: x <= q
+                u32 d2 = xh[j] - q2;                                    // (x + 0x8000) - q per half; bit 15 / 31: x >= q
                 // rotate right by one, then take bits 15 and 31 from the difference (the compiler's own rendering of
                 // this costs a third instruction)
-                asm("v_alignbit_b32 %0, %0, %0, 1\n\tv_bfi_b32 %0, %2, %1, %0" : "+v"(na) : "v"(d1), "s"(H));
-                asm("v_alignbit_b32 %0, %0, %0, 1\n\tv_bfi_b32 %0, %2, %1, %0" : "+v"(nb_) : "v"(d2), "s"(H));
+                ST_SHIFT_IN(na, d1);
+                ST_SHIFT_IN(nb_, d2);
             }
             strict_store_masks(o, b, k, W32, n, i, (~na | nanbits) & valid, (~nb_ | nanbits) & valid, valid);
         }
