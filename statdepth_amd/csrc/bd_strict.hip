@@ -1610,27 +1610,26 @@ int launch_bd_strict_classes(const double *Y, i64 T, i64 n, const i64 *targets, 
     switch ((int)T) {
         case 1: ST_CL_LAUNCH(1) break;
         case 2: ST_CL_LAUNCH(2) break;
-        case 3: ST_CL_LAUNCH(3) break;
-        // T = 4, 5 without NaN: the workgroup form (lanes = points, shared histograms: 10^5 x 4 / 5 in 6.7 / 8.5 ms against 21 / 46
-        // with a histogram per lane); with NaN the four-state lane kernel.  Cross-check builds, SD_STRICT_LANECLASS = 1: the
-        // lane kernel for both.
+        case 3:
+        // T = 3, 4, 5 without NaN: the workgroup form (lanes = points, shared histograms: 10^5 x 3 / 4 / 5 in 4.9 / 6.7 / 8.5 ms against
+        // 10.7 / 21 / 46 with a histogram per lane; 10^6 x 3: 427 against 506 ms); with NaN the four-state lane kernel.  Cross-check
+        // builds, SD_STRICT_LANECLASS = 1: the lane kernel for both.
         case 4:
         case 5:
             if (xswitch("SD_STRICT_LANECLASS") == 1) {
-                if (T == 4) { ST_CL_LAUNCH(4) } else { ST_CL_LAUNCH(5) }
+                if (T == 3) { ST_CL_LAUNCH(3) } else if (T == 4) { ST_CL_LAUNCH(4) } else { ST_CL_LAUNCH(5) }
                 break;
             }
-            if (T == 4) {
-                int rc = launch_class_wg<4>(Y, n, targets, Q, m, flag, out, jcols, s);
-                if (rc) return rc;
-                hipLaunchKernelGGL((strict_class_kernel<4, true>), dim3((unsigned)((m + st_cl_threads(4, true) - 1) / st_cl_threads(4, true))),
-                                   dim3(st_cl_threads(4, true)), 0, s, Y, n, targets, Q, m, (const u32 *)flag, out, jcols);
-            } else {
-                int rc = launch_class_wg<5>(Y, n, targets, Q, m, flag, out, jcols, s);
-                if (rc) return rc;
-                hipLaunchKernelGGL((strict_class_kernel<5, true>), dim3((unsigned)((m + st_cl_threads(5, true) - 1) / st_cl_threads(5, true))),
-                                   dim3(st_cl_threads(5, true)), 0, s, Y, n, targets, Q, m, (const u32 *)flag, out, jcols);
+#define ST_CL_WG(TT_)                                                                                                          \
+            {                                                                                                                  \
+                int rc = launch_class_wg<TT_>(Y, n, targets, Q, m, flag, out, jcols, s);                                       \
+                if (rc) return rc;                                                                                             \
+                hipLaunchKernelGGL((strict_class_kernel<TT_, true>),                                                           \
+                                   dim3((unsigned)((m + st_cl_threads(TT_, true) - 1) / st_cl_threads(TT_, true))),            \
+                                   dim3(st_cl_threads(TT_, true)), 0, s, Y, n, targets, Q, m, (const u32 *)flag, out, jcols);   \
             }
+            if (T == 3) ST_CL_WG(3) else if (T == 4) ST_CL_WG(4) else ST_CL_WG(5)
+#undef ST_CL_WG
             break;
         default: return fail(SD_ERR_UNSUPPORTED, "the class kernel covers up to five timepoints");
     }
@@ -1648,7 +1647,7 @@ int launch_bd_strict_classes(const double *Y, i64 T, i64 n, const i64 *targets, 
 // ---------------------------------------------------------------------------------------------------
 constexpr int SCW_PTS = 4;
 template <int TT> struct ScwCfg {
-    static constexpr int NC = TT == 4 ? 81 : (TT == 5 ? 243 : (TT == 6 ? 729 : (TT == 7 ? 2187 : 6561)));
+    static constexpr int NC = TT == 3 ? 27 : (TT == 4 ? 81 : (TT == 5 ? 243 : (TT == 6 ? 729 : (TT == 7 ? 2187 : 6561))));
     static constexpr int G = TT <= 5 ? 16 : (TT <= 7 ? 8 : 4);          // (T >= 6:) 46 / 70 / 105 KB of histograms
     static constexpr int NT = TT == 8 ? 1024 : 512;                     // three / two / one workgroup per CU
     // few classes: the lanes of a wave meet on the same counter (most points are strictly above or below in every coordinate:
@@ -1656,7 +1655,8 @@ template <int TT> struct ScwCfg {
     // T = 6: 8 targets x 2 copies against 16 x 1: 10.1 against 15.6 ms on random walks (correlated coordinates: fewer classes
     // occur), the same on independent ones; T = 7 / 8 with copies (4 x 2 / 2 x 2 targets): 13.2 / 23.3 against 15.1 / 20.0 on walks,
     // 13.1 / 23.4 against 12.2 / 18.5 on independent coordinates -- not taken
-    static constexpr int R = TT == 4 ? 8 : (TT == 5 ? 4 : (TT == 6 ? 2 : 1));
+    // (T = 3: 16 copies; 8 the same, 32 slower; 32 targets per workgroup slower)
+    static constexpr int R = TT == 3 ? 16 : (TT == 4 ? 8 : (TT == 5 ? 4 : (TT == 6 ? 2 : 1)));
     static constexpr size_t LDS = (size_t)G * R * NC * 4;
 };
 __device__ __forceinline__ double scw_uniform(double v) {               // a wave-uniform double into SGPRs
