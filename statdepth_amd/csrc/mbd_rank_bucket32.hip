@@ -3,8 +3,12 @@
 // Same integers as rank_bucket_kernel (mbd_rank_bucket.hip), the pairwise kernel and the reference's enumeration
 // (_functional.py:246-251, _containment.py:75-77).  The fp64 kernel keeps one row per CU in LDS and its five
 // barrier-separated phases leave the VALU idle while the LDS works and the other way round (SQ counters: VALU busy 57 %,
-// LDS busy 37 %, together the kernel's whole time).  Here a row's keys live in LDS as 32-bit images
-//     q(x) = trunc((x - lo) * (2^31 - 256) / (hi - lo))          -- non-decreasing in x whatever the data
+// LDS busy 37 %, together the kernel's whole time).  Here a row's keys live in LDS as 31-bit images q(x), non-decreasing in x
+// whatever the data and whatever the map's constants (round 4: a THREE-PIECE map -- a linear core of 14 336 buckets over the
+// row's range, clipped to a central bracket taken from a sample of 1 024 keys when the range is much wider than the bulk
+// (heavy tails, outlying curves), and below and above the core 1 024 buckets each for a float-like code of the distance to
+// the core's edge, bits(d + c) - bits(c) with c = core width / 448: linear with the core's slope next to the edge, halving
+// per octave, 32 octaves; every piece is monotone and the pieces are ordered),
 // so that a row of up to 11 264 curves + its 16 384-bucket histogram take 77 KiB and two 512-thread workgroups, half a
 // row apart in phase, share a CU: one's compares run under the other's LDS traffic.  Order is decided by the images
 // wherever they differ; keys whose images coincide (two values within range / 2^31, or equal values) are NOT ranked
@@ -40,7 +44,12 @@ constexpr int R32_NT = 512, R32_NW = 8;
 constexpr int R32_LCAP = 64;                    // set-aside keys per workgroup before it hands all its rows over
 constexpr int R32_LIST_WORDS = 1 + 2 * R32_LCAP;   // a workgroup's list in the workspace: count, keys, (B0 | E0 << 16)
 constexpr int R32_PAD = 12;                     // sentinel images behind the keys (two quads past the last partial quad)
-constexpr double R32_TOP = 2147483392.0;        // 2^31 - 256: the largest key image (31 bits: y < q <=> bit 31 of y - q)
+constexpr u32 R32_TB = 1024;                    // buckets of each tail
+constexpr int R32_TSH = 30;                     // tail code = (bits(d + c) - bits(c)) >> 30: 2^22 codes = 32 buckets per octave
+constexpr double R32_CDIV = 1.0 / 448.0;        // c = core width / 448: the first octave continues the core's slope (32 * 448 = 14 336)
+#ifndef R32_BETA
+#define R32_BETA 2.0                             // the central bracket of the sample is widened by this many spans on either side
+#endif
 constexpr u32 R32_SENT = 0x7FFFFFFFu;           // sentinel image behind the keys: above every key image, below 2^31
 
 template <int E, int LNB>
@@ -48,7 +57,11 @@ struct R32Cfg {
     static constexpr int NT = R32_NT, NW = R32_NW, NB = 1 << LNB;
     static constexpr int QW = NB / 2 / NT / 4;                  // 16-byte quads of histogram words per thread
     static_assert(QW >= 1 && NB / 2 == QW * 4 * NT, "whole quads of histogram words per thread");
-    static constexpr size_t HDR = 4 * NW * 8 + NW * 4 + 32 + (size_t)R32_LCAP * 8;
+    static constexpr int SH = 31 - LNB;
+    static constexpr u32 C0 = R32_TB << SH, C1 = ((u32)NB - R32_TB) << SH;   // images of the core: [C0, C1)
+    static constexpr u32 NANIMG = ((u32)NB + 2u) << SH;         // a NaN's image: its bucket is the dummy counter NB + 2
+    static_assert(LNB == 14, "the first tail octave continues the core's slope for 14 336 core buckets");
+    static constexpr size_t HDR = 8 * NW * 8 + NW * 4 + 32 + (size_t)R32_LCAP * 8;
     static_assert(HDR % 16 == 0, "the histogram starts on a 16-byte boundary");
     static __host__ __device__ constexpr int al4(int n) { return (n + 3) & ~3; }
     static __host__ __device__ constexpr int dummy_pos(int n) { return al4(n) + R32_PAD; }
@@ -61,11 +74,12 @@ __global__ __launch_bounds__(R32_NT, 4) void rank_bucket32_kernel(const double *
                                                                  u32 *__restrict__ gate, u32 epoch, u64 *__restrict__ out_zero,
                                                                  u32 *__restrict__ listbuf) {
     using C = R32Cfg<E, LNB>;
-    constexpr int NT = C::NT, NW = C::NW, NB = C::NB, QW = C::QW, SH = 31 - LNB;
+    constexpr int NT = C::NT, NW = C::NW, NB = C::NB, QW = C::QW, SH = C::SH;
+    constexpr u32 C0 = C::C0, C1 = C::C1, NANIMG = C::NANIMG;
     extern __shared__ double Sm[];
     const int n = (int)n64;
-    double *red = Sm;                                                 // [2][NW][2] min/max partials
-    u32 *wtot = reinterpret_cast<u32 *>(red + 4 * NW);                // [NW]
+    double *red = Sm;                                                 // [2][NW][4] min / max of the row, central bracket of its sample
+    u32 *wtot = reinterpret_cast<u32 *>(red + 8 * NW);                // [NW]
     u32 *misc = wtot + NW;                                            // [0]: set-aside keys so far, [1]: running sum of the ranks
     u32 *lkey = misc + 8, *lbe = lkey + R32_LCAP;                     // (row index << 14 | curve), B0 | E0 << 16
     u32 *H = reinterpret_cast<u32 *>(reinterpret_cast<char *>(Sm) + C::HDR);
@@ -106,6 +120,11 @@ __global__ __launch_bounds__(R32_NT, 4) void rank_bucket32_kernel(const double *
     u32 acc[E];
 #pragma unroll
     for (int e = 0; e < E; ++e) acc[e] = 0;
+    // the sample of a row: one key per thread at evenly spaced curve indices -- thread t takes position j = 397 t mod 512 of the 512,
+    // so that the 16 lanes of a DPP row hold keys from all over the curve index (curves ordered by level would otherwise make
+    // every group one level).  The innermost of the 32 groups' minima and maxima bracket the bulk (about the quartiles).
+    double smp;
+    auto sample_issue = [&](i64 r) { smp = Y[(row0 + r) * n + (((((u32)t * 397u) & 511u) * (u32)n) >> 9)]; };
     auto row_range = [&](int parity) {
         double mn = INF, mx = -INF;
 #pragma unroll
@@ -115,8 +134,21 @@ __global__ __launch_bounds__(R32_NT, 4) void rank_bucket32_kernel(const double *
         }
         mn = rb_wave_allreduce<false>(mn);
         mx = rb_wave_allreduce<true>(mx);
-        double *rp = red + parity * 2 * NW;
-        if ((t & 63) == 63) { rp[2 * (t >> 6)] = mn; rp[2 * (t >> 6) + 1] = mx; }
+        // the sample's central bracket, in float (it only places the core: the map is monotone whatever it says): a NaN drops
+        // out of v_min / v_max, a group without a value keeps +-inf and switches the bracket off
+        const float sf = (float)smp;
+        const float rmn = rb_row_allreduce_f32<false>(sf == sf ? sf : __builtin_huge_valf());
+        const float rmx = rb_row_allreduce_f32<true>(sf == sf ? sf : -__builtin_huge_valf());
+        auto rl = [](float v, int l) -> float { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); };
+        const float imn = fmaxf(fmaxf(rl(rmn, 0), rl(rmn, 16)), fmaxf(rl(rmn, 32), rl(rmn, 48)));
+        const float imx = fminf(fminf(rl(rmx, 0), rl(rmx, 16)), fminf(rl(rmx, 32), rl(rmx, 48)));
+        double *rp = red + parity * 4 * NW;
+        if ((t & 63) == 63) {
+            double *wp = rp + 4 * (t >> 6);
+            wp[0] = mn; wp[1] = mx;
+            reinterpret_cast<float *>(wp + 2)[0] = imn;
+            reinterpret_cast<float *>(wp + 2)[1] = imx;
+        }
     };
 #ifdef R32_STAMPS                                  // timing experiments: cycles per phase, one wave
     long long stamp[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tlast = (long long)__builtin_readcyclecounter();
@@ -140,10 +172,11 @@ __global__ __launch_bounds__(R32_NT, 4) void rank_bucket32_kernel(const double *
         // the second launch (gate[1] = epoch << 8 | count; block-uniform scalar load, a few rows stale at worst)
         if (rowidx && t == 0) misc[3] = __hip_atomic_load(gate + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ONE load per workgroup
         __builtin_amdgcn_s_setprio(R32_PRIO_LDS);                     // latency-bound phases go first, the compares of the member
-        load_row(r);                                                  // pass (the other workgroup's, half a row away) fill in                                                  // the other workgroup of this CU works under this latency
+        sample_issue(r);
+        load_row(r);                                                  // pass (the other workgroup's, half a row away) fill in
         row_range(par);
         R32_MARK(1)
-        double *redp = red + par * 2 * NW;
+        double *redp = red + par * 4 * NW;
         par ^= 1;
         __syncthreads();                                              // barrier 1 (histogram is zero, S is free)
         R32_MARK(2)
@@ -151,27 +184,73 @@ __global__ __launch_bounds__(R32_NT, 4) void rank_bucket32_kernel(const double *
             const u32 w = misc[3];
             if ((w >> 8) == (epoch & 0xFFFFFFu) && (w & 0xFFu) >= 8u) { stop = true; break; }
         }
-        double lo, hi;
+        double lo, hi;                                                // the row's minimum and maximum, then the core of the map
+        double mscale, moff, mc;
+        u64 mcb;
+        u32 mc0, mcw;                                                 // the core's first image and its width in images
+        bool go, bad;
         {
-            const double2 p = reinterpret_cast<const double2 *>(redp)[lane & (NW - 1)];
+            const double2 p = reinterpret_cast<const double2 *>(redp)[2 * (lane & (NW - 1))];
+            const float2 pb = reinterpret_cast<const float2 *>(redp + 4 * (lane & (NW - 1)) + 2)[0];
             lo = rb_readlane_f64(rb_row_allreduce<false>(p.x), 0);
             hi = rb_readlane_f64(rb_row_allreduce<true>(p.y), 0);
-            // outlier-robust range, as in rank_bucket_kernel: the innermost of the waves' minima and maxima bracket the bulk
-            const float l2 = rb_row_allreduce_f32<true>((float)p.x), h2 = rb_row_allreduce_f32<false>((float)p.y);
-            const double lo2 = (double)__int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(l2)));
-            const double hi2 = (double)__int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(h2)));
-            const double sp = hi2 - lo2;
-            if (sp > 0.0 && sp < INF && (hi - lo) > 8.0 * sp) {       // block-uniform
-                const double nlo = lo2 - 1.5 * sp, nhi = hi2 + 1.5 * sp;
-                lo = nlo > lo ? nlo : lo;
-                hi = nhi < hi ? nhi : hi;
+            const double imn = (double)__int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(rb_row_allreduce_f32<true>(pb.x))));
+            const double imx = (double)__int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(rb_row_allreduce_f32<false>(pb.y))));
+            // hi < lo: no value at this timepoint (every curve NaN), nothing is contained.  Else a row with an infinity, an
+            // overflowing range or all values equal (one bucket) is handed over.
+            const bool fin = (hi > lo) && (lo > -INF) && (hi < INF) && ((hi - lo) < INF);
+            bad = !fin && (hi >= lo);
+            // the core: the row's range, clipped to the sample's central bracket widened by R32_BETA spans on either side (a
+            // light-tailed row keeps its whole range and never sees the tail code; heavy tails and outlying curves go to the tails)
+            const double si = imx - imn;
+            u32 c0 = 256u, c1 = 0x7FFFFE00u;                          // a light-tailed row: the core takes the whole image range
+            if (fin && si > 0.0 && si < INF && (hi - lo) > (1.5 * (1.0 + 2.0 * R32_BETA)) * si) {   // block-uniform: the range is
+                const double lo2 = imn - R32_BETA * si, hi2 = imx + R32_BETA * si;                  // much wider than the bulk
+                lo = lo2 > lo ? lo2 : lo;
+                hi = hi2 < hi ? hi2 : hi;
+                c0 = C0;
+                c1 = C1;
             }
+            mc0 = c0;
+            mcw = c1 - c0;
+            const double wc = hi - lo;
+            mscale = ((double)mcw - 64.0) / wc;                       // the largest key of an unclipped row stays inside the core
+            moff = __builtin_fma(-lo, mscale, (double)c0);
+            mc = wc * R32_CDIV;
+            mcb = (u64)__double_as_longlong(mc);
+            go = fin && (wc > 0.0) && (mscale < INF) && (mc > 0.0);
+            bad = bad || (fin && !go);
         }
-        const double scale = (hi > lo) ? R32_TOP / (hi - lo) : 0.0;
-        // hi < lo: no value at this timepoint (every curve NaN), nothing is contained.  Else a row with an infinity, an
-        // overflowing range or all values equal (scale 0: one bucket) is handed over.
-        const bool go = (hi > lo) && (scale < INF) && (lo > -INF) && (hi < INF);
-        bool bad = !go && (hi >= lo);
+        // images of four keys: core keys cost fma + cvt + the core test; the tail code is computed only when some lane of the wave
+        // has a key outside the core (or a NaN: cvt gives 0)
+        auto convert4 = [&](const double (&xv)[4], u32 (&q)[4]) {
+            bool anyout = false;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const double u = __builtin_fma(xv[i], mscale, moff);
+                u32 qi;
+                asm("v_cvt_u32_f64 %0, %1" : "=v"(qi) : "v"(u));      // saturating: below -> 0, above -> 2^32 - 1, NaN -> 0
+                q[i] = qi;
+                anyout = anyout || (qi - mc0 >= mcw);
+            }
+            if (__ballot(anyout) != 0) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const bool outc = q[i] - mc0 >= mcw, low = q[i] < mc0;
+                    double d = low ? lo - xv[i] : xv[i] - hi;
+                    d = rb_mm<true>(d, 0.0);                          // a key the rounding put just outside: code 0
+                    const u64 tc = ((u64)__double_as_longlong(d + mc) - mcb) >> R32_TSH;
+                    // below the core: mc0 - 1 downwards; above: from the core's end upwards; clamped to what is left of the
+                    // image range (a clipped core leaves 1 024 buckets on either side, an unclipped one a few images: only a
+                    // key the rounding put just outside comes here then)
+                    const u32 room = low ? mc0 - 1u : 0x7FFFFEFFu - (mc0 + mcw);
+                    const u32 tcc = tc < (u64)room ? (u32)tc : room;
+                    u32 qt = low ? (mc0 - 1u) - tcc : (mc0 + mcw) + tcc;
+                    qt = (xv[i] == xv[i]) ? qt : NANIMG;
+                    q[i] = outc ? qt : q[i];
+                }
+            }
+        };
         u32 sl[(E + 3) / 4];
         if (go) {
             // ---- (1) image, bucket, slot: trunc(min(fl(fl(x - lo) * scale), TOP)), negative -> 0, is non-decreasing in x ----
@@ -182,16 +261,23 @@ __global__ __launch_bounds__(R32_NT, 4) void rank_bucket32_kernel(const double *
             for (int e0 = 0; e0 < E; e0 += 8) {
                 u32 old[8];
 #pragma unroll
+                for (int h = 0; h < 8; h += 4) {
+                    if (e0 + h < E) {
+                        double xv[4];
+                        u32 q[4];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) xv[i] = e0 + h + i < E ? x[e0 + h + i] : x[e0 + h];
+                        convert4(xv, q);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            if (e0 + h + i < E) kb[e0 + h + i] = q[i];
+                    }
+                }
+#pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     const int e = e0 + i;
                     if (e < E) {
-                        const double xv = x[e];
-                        double u = (xv - lo) * scale;
-                        u = u < R32_TOP ? u : R32_TOP;                // NaN -> TOP (bucket overridden below)
-                        u32 qi;
-                        asm("v_cvt_u32_f64 %0, %1" : "=v"(qi) : "v"(u));   // saturating: below the range -> 0
-                        kb[e] = qi;
-                        const u32 b = (xv == xv) ? (qi >> SH) : (u32)(NB + 2);
+                        const u32 b = kb[e] >> SH;                    // a NaN's image: the dummy counter NB + 2
                         old[i] = atomicAdd(&H[b >> 1], 1u << ((b & 1u) * 16u));
                     }
                 }
@@ -265,7 +351,8 @@ __global__ __launch_bounds__(R32_NT, 4) void rank_bucket32_kernel(const double *
                     const u32 base = H16[b], end = H16[b1];
                     const bool isk = e < E - 2 || t + e * NT < n;
                     S[isk ? base + slot : (u32)DUMMY] = kb[e];
-                    bc[e] = base | ((end - base) << 14);
+                    // a slot beyond n carries the NaN image: its "bucket" is the dummy counter, not a range of S -- one key at 0
+                    bc[e] = isk ? base | ((end - base) << 14) : (1u << 14);
                 }
             }
             R32_MARK(7)
@@ -489,12 +576,13 @@ __global__ __launch_bounds__(R32_NT, 4) void rank_bucket32_kernel(const double *
     }
 #ifdef R32_STAMPS
     __syncthreads();
-    if (t0 == 0) {
-        u32 *dbg = listbuf + (size_t)gridDim.x * R32_LIST_WORDS + (size_t)blockIdx.x * 4;
+    if ((t0 & 63) == 0 && (t0 == 0 || t0 == NT - 64)) {                // the oldest and the youngest wave of the workgroup
+        u32 *dbg = listbuf + (size_t)gridDim.x * R32_LIST_WORDS + (size_t)blockIdx.x * 32 + (t0 ? 16 : 0);
         dbg[0] = (u32)((long long)__builtin_readcyclecounter() - t_entry);
         dbg[1] = (u32)rt_entry;
         dbg[2] = (u32)__builtin_amdgcn_s_memrealtime();
         dbg[3] = misc[0] | (rowidx << 16);
+        for (int i = 0; i < 10; ++i) dbg[4 + i] = (u32)stamp[i];
     }
 #endif
 }
@@ -525,7 +613,11 @@ static int launch32_cfg(const double *Y, i64 n, i64 row0, i64 rows, u32 *partial
 
 // rows [row0, row0 + rows): u32 partial totals of every curve per workgroup (G blocks of n), flags of the rows left to the
 // fp64 kernel in rowflag[rows], *gate = epoch when there is any
-size_t rank_bucket32_list_bytes(int G) { return (size_t)G * R32_LIST_WORDS * 4 + (size_t)G * 16; }
+#ifdef R32_STAMPS
+size_t rank_bucket32_list_bytes(int G) { return (size_t)G * R32_LIST_WORDS * 4 + (size_t)G * 128; }
+#else
+size_t rank_bucket32_list_bytes(int G) { return (size_t)G * R32_LIST_WORDS * 4; }
+#endif
 
 int launch_rank_bucket32(const double *Y, i64 n, i64 row0, i64 rows, u32 *partial, unsigned char *rowflag, u32 *gate, u32 epoch,
                          u64 *out_zero, u32 *listbuf, int G, hipStream_t s) {

@@ -14,7 +14,8 @@ bad = 0
 for c in range(cases):
     n = int(rng.integers(3073, 11265))
     T = int(rng.choice([256, 257, 300, 511, 512, 513, 700, 1024]))
-    kind = rng.choice(["walk", "normal", "round1", "round2", "ints", "lognormal", "mixed"])
+    kind = rng.choice(["walk", "normal", "round1", "round2", "ints", "lognormal", "mixed", "cauchy", "t3", "levels", "spikes", "tiny",
+                       "huge", "clusters", "stride", "edge"])
     X = rng.normal(size=(T, n))
     if kind == "walk": X = X.cumsum(axis=0)
     elif kind == "round1": X = np.round(X.cumsum(axis=0), 1)
@@ -25,6 +26,22 @@ for c in range(cases):
         X = X.cumsum(axis=0)
         X[::3] = np.round(X[::3], 1)                                  # quantised rows between continuous ones
         X[1::7, : n // 2] = np.round(X[1::7, : n // 2], 0)            # half a row quantised: ties mixed with distinct values
+    elif kind == "cauchy": X = rng.standard_cauchy(size=(T, n))     # heavy tails: the tail codes of the three-piece map
+    elif kind == "t3": X = rng.standard_t(3, size=(T, n)) * 10.0
+    elif kind == "levels": X = np.sort(rng.standard_t(3, size=n))[None, :] * 30.0 + X.cumsum(axis=0) * 0.05   # curves ordered by level
+    elif kind == "spikes":                                            # a few per cent of the entries far outside the bulk, either side
+        X = X.cumsum(axis=0); m = rng.random(size=X.shape) < 0.03; X[m] *= rng.choice([-1e6, 1e3, 1e6], size=int(m.sum()))
+    elif kind == "tiny": X = X * 1e-310                               # denormals: the core's width underflows
+    elif kind == "huge": X = X * 1e300 * rng.choice([1.0, 1e7])       # overflowing ranges
+    elif kind == "clusters":                                          # tight clusters far apart: the sample's bracket sits in one of them
+        X = X * 1e-6 + rng.choice([0.0, 1.0, 1e3], size=n, p=[0.8, 0.15, 0.05])[None, :]
+    elif kind == "stride":                                            # a pattern in the curve index that the evenly spaced sample may miss or hit
+        X = X.cumsum(axis=0); X[:, :: int(rng.choice([2, 5, 10, 11, 64]))] += rng.choice([50.0, 1e4])
+    elif kind == "edge":                                              # many keys exactly at and a hair beyond the row's extremes
+        X = X.cumsum(axis=0); hi = X.max(axis=1); lo = X.min(axis=1)
+        for _ in range(40):
+            r = int(rng.integers(0, T)); j = rng.integers(0, n, size=6)
+            X[r, j[:2]] = hi[r]; X[r, j[2:4]] = np.nextafter(hi[r], np.inf); X[r, j[4]] = lo[r]; X[r, j[5]] = np.nextafter(lo[r], -np.inf)
     for _ in range(int(rng.integers(0, 6))):                          # image collisions / exact ties in single rows
         r = int(rng.integers(0, T)); a, b = rng.integers(0, n, size=2)
         X[r, a] = X[r, b] * (1 + rng.choice([0.0, 1e-16, 1e-15, 1e-13]))

@@ -4,6 +4,7 @@ usage: time_rank.py [n] [T] [reps]; prints ms per call for each SD_RB_DBG level 
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import torch
 from statdepth_amd import engine, _native
 if os.environ.get("SD_LIB"):                     # experiments: another build of the library (this tool only)
@@ -11,19 +12,8 @@ if os.environ.get("SD_LIB"):                     # experiments: another build of
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
 T = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 30
-X = np.random.default_rng(1234).normal(size=(T, n)).cumsum(axis=0)
-if os.environ.get("SD_TIES"):
-    X = np.round(X, 1)
-if os.environ.get("SD_SORTED"):                  # curves ordered by level (normal / t3): the waves' subsets are stratified
-    g = np.random.default_rng(3)
-    lev = np.sort(g.normal(size=n) if os.environ["SD_SORTED"] == "normal" else g.standard_t(3, size=n))
-    X = lev[None, :] * 30.0 + X * 0.05
-if os.environ.get("SD_OUTLIER"):                 # a few curves far outside the others' range
-    X[:, :int(os.environ["SD_OUTLIER"])] *= float(os.environ.get("SD_OUTLIER_SCALE", "1e6"))
-if os.environ.get("SD_OUTLIER_RANDOM"):          # ... at random positions (every wave of the bucket kernel gets some)
-    X[:, np.random.default_rng(9).choice(n, size=int(os.environ["SD_OUTLIER_RANDOM"]), replace=False)] *= 1e6
-if os.environ.get("SD_CAUCHY"):                  # heavy tails at every timepoint
-    X = np.random.default_rng(5).standard_cauchy(size=(T, n))
+from _rankdata import rank_data
+X = rank_data(n, T)
 Xd = engine.to_device_matrix(X)
 ROT = int(os.environ.get("SD_ROTATE", "1"))      # > 1: that many distinct matrices in rotation (every call streams from HBM)
 Xs = [Xd] + [engine.to_device_matrix(X + float(k)) for k in range(1, ROT)]
