@@ -167,7 +167,7 @@ def extras_single_gpu(torch, dev, stream, lib, check, ALGOS, oracle, reps=10):
                     "roofline": {"bound": "hbm", "achieved": balg / (ms * 1e-3) / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                                  "frac": balg / (ms * 1e-3) / HBM_PEAK, "traffic": None, "algorithmic_bytes": balg,
                                  "kernels_of_step": ["bucket_setup_kernel", "bucket_partition3_kernel", "bucket_rank32_kernel",
-                                                     "rank_accumulate2_kernel"]}}
+                                                     "rank_accumulate_h8_kernel"]}}
         del X, res
     Xh = np.round(np.random.default_rng(1234).normal(size=(1000, 10000)).cumsum(axis=0), 1)
     dup = np.random.default_rng(7).choice(10000, size=100, replace=False)
@@ -176,6 +176,13 @@ def extras_single_gpu(torch, dev, stream, lib, check, ALGOS, oracle, reps=10):
     assert (res.cpu().numpy() == oracle.mbd_counts_ranksort(Xh, 2)).all(), "ties variant"
     out["config2_ties"] = {"workload": "config 2 rounded to 0.1 + 1 % duplicated curves", "ms": ms,
                            "curve_pairs_per_s": rate(1000, 10000, ms), "checked_targets": 10000}
+    # heavy tails at every timepoint (Cauchy rows): the three-piece key map's tail codes (round 4; every row went to the fp64
+    # sort before: 0.24 - 0.27 ms)
+    Xh = np.random.default_rng(5).standard_cauchy(size=(1000, 10000))
+    ms, res = mbd_ms(torch.from_numpy(Xh).to(dev))
+    assert (res.cpu().numpy() == oracle.mbd_counts_ranksort(Xh, 2)).all(), "cauchy variant"
+    out["config2_cauchy"] = {"workload": "config 2's shape, standard Cauchy entries (heavy tails at every timepoint)", "ms": ms,
+                             "curve_pairs_per_s": rate(1000, 10000, ms), "checked_targets": 10000}
     # the same config-2 call from a HOST array through the Python engine: H2D of the 80 MB matrix + workspace + kernels + D2H
     # (PCIe-inclusive; never the headline value, which starts with the inputs resident in HBM)
     Xw = np.random.default_rng(1234).normal(size=(1000, 10000)).cumsum(axis=0)
@@ -593,7 +600,8 @@ def main():
         mode = args.mode if args.mode != "auto" else model["choice"]
         line = {
             "metric": "curve-pairs/sec (MBD)", "value": value, "unit": "curve-pairs/s",
-            "n_gpus": N, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "n_gpus": N, "steps": args.steps, "warmup": args.warmup, "untimed_steps": clock_warm + args.warmup,
+            "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"MBD J={J}: {n} curves x {T} timepoints (n_loc={n_loc} targets per GPU), fp64 "
@@ -606,6 +614,7 @@ def main():
             "pair_timepoints_per_s": value * T,
             "clock_warmup_steps": clock_warm,
             "mode": {"used": mode, "cost_model_seconds": {"time": model["time"], "targets": model["targets"]},
+                     "predicted_step_ms": (model[mode] * 1e3 if mode in model else None), "measured_step_ms": ms_per_step,
                      "note": "statdepth_amd.distributed.mode_cost_model: exchange over one xGMI link per peer + the measured "
                              "single-GPU ranking rates; mode='auto' takes the cheaper decomposition"},
             "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",

@@ -427,6 +427,10 @@ __global__ __launch_bounds__(R32_NT, 4) void rank_bucket32_kernel(const double *
                     }
                 }
             }
+#if defined(R32_SECPRIO)                          // timing experiment: the workgroup dispatched second to a CU one level up in the member pass
+            if (blockIdx.x >= gridDim.x / 2) __builtin_amdgcn_s_setprio(R32_PRIO_VALU + 1);
+            else
+#endif
             __builtin_amdgcn_s_setprio(R32_PRIO_VALU);
             {                                                         // the histogram is dead until the next row's atomics
                 uint4 *Hz = reinterpret_cast<uint4 *>(H) + wave * (64 * QW);

@@ -3,6 +3,8 @@
 Everything numerical happens in libstatdepth_hip.so; this module moves data to HBM
 (torch is the allocator / stream provider), sizes workspaces and calls the C ABI.
 """
+import threading
+
 import numpy as np
 
 from . import _native
@@ -79,36 +81,49 @@ def to_device_matrix(X, device=None):
     return DeviceMatrix(t.from_numpy(A.T).to(dev).t())
 
 
-# One grow-only scratch buffer per device, reused by every call (the C ABI takes the workspace as an argument and keeps
-# nothing in it between calls): a repeated call of the same shape pays no allocation and no allocator round trip.  Buffers
-# above _WS_KEEP bytes are handed out once and not kept (strict depth at large n asks for GiBs).
+# One grow-only scratch buffer per (device, stream, host thread), reused by every call (the C ABI takes the workspace as an
+# argument and keeps nothing in it between calls): a repeated call of the same shape pays no allocation and no allocator round
+# trip.  The launchers are multi-launch pipelines with live state in the buffer between their launches, and ctypes releases
+# the GIL: two host threads on ONE stream must not share a buffer (their launches may interleave), hence the thread in the key.
+# Results handed out with return_tensor=True are separate tensors and stay valid.  Buffers above _WS_KEEP bytes are handed
+# out once and not kept (strict depth at large n asks for GiBs); at most _WS_SLOTS buffers are kept, least recently used
+# first out (side streams and worker threads that are gone).
 _WS_KEEP = 2 << 30
+_WS_SLOTS = 8
 _ws_cache = {}
+_ws_lock = threading.Lock()
 
 
 def _ws_key(dev):
-    # per (device, stream): calls on one stream run in order and may share the buffer, calls on two streams may overlap
+    # per (device, stream, thread): calls of one thread on one stream run in order and may share the buffer
     t = torch()
     idx = dev.index if dev.index is not None else t.cuda.current_device()
-    return (idx, t.cuda.current_stream(dev).cuda_stream)
+    return (idx, t.cuda.current_stream(dev).cuda_stream, threading.get_ident())
 
 
 def _workspace(dev, nbytes):
     t = torch()
     nbytes = max(int(nbytes), 8)
     key = _ws_key(dev)
-    buf = _ws_cache.get(key)
-    if buf is not None and buf.numel() >= nbytes:
-        return buf
+    with _ws_lock:
+        buf = _ws_cache.pop(key, None)
+        if buf is not None and buf.numel() >= nbytes:
+            _ws_cache[key] = buf                                      # most recently used last
+            return buf
+    del buf                                                           # the smaller buffer goes back before the larger one is asked for
     new = t.empty(nbytes, dtype=t.uint8, device=dev)
     if nbytes <= _WS_KEEP:
-        _ws_cache[key] = new
+        with _ws_lock:
+            _ws_cache[key] = new
+            while len(_ws_cache) > _WS_SLOTS:
+                _ws_cache.pop(next(iter(_ws_cache)))
     return new
 
 
 def release_workspace():
     """Drop the cached scratch buffers (they are plain torch tensors; the caching allocator gets them back)."""
-    _ws_cache.clear()
+    with _ws_lock:
+        _ws_cache.clear()
 
 
 def _check_members(mem, tg, n):

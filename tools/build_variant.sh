@@ -9,7 +9,7 @@ cd $root/statdepth_amd/csrc
 mkdir -p ../lib/obj_var
 /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -I$root/include -I. -Wall -Wno-unused-function -ffp-contract=off "$@" -c $src.hip -o ../lib/obj_var/${src}_$name.o
 objs=""
-for o in sd_api mbd_pairwise mbd_rank_bucket mbd_rank_bucket32 bd_strict l1_depth simplex band_enum xcheck mbd_rank_ab mbd_rank_big; do
+for o in sd_api mbd_pairwise mbd_rank_bucket mbd_rank_bucket32 bd_strict bd_strict_grid l1_depth simplex band_enum xcheck mbd_rank_ab mbd_rank_big; do
   if [ "$o" = "$src" ]; then objs="$objs ../lib/obj_var/${src}_$name.o"; else objs="$objs ../lib/obj/$o.o"; fi
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../lib/libsd_$name.so $objs

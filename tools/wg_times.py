@@ -18,7 +18,7 @@ Xd = engine.to_device_matrix(X)
 for _ in range(3):
     engine.mbd_counts(Xd, None, 2, algo="rank", return_tensor=True)
 torch.cuda.synchronize()
-ws = list(engine._ws_cache.values())[0]
+ws = list(engine._ws_cache.values())[-1]
 cus = torch.cuda.get_device_properties(0).multi_processor_count
 G = min(T, 2 * cus)
 off = 2 * cus * ((n + 3) // 4 * 4) * 4 + (T + 63) // 64 * 64 + 64 + G * 129 * 4
