@@ -6,11 +6,14 @@ _pointcloud.py:45), so rank r owns a block of curves, contributes it to an all-g
 its own curves against the gathered set.  Integer totals do not depend on the number of
 ranks.  The only other communication is the optional gather of the (tiny) results.
 """
-import os
-
 import numpy as np
 
 from . import engine
+
+# Pieces the exchanges are cut into so that one piece travels (RCCL's stream) while the one before it is computed on (the
+# current stream): sub-slices of every rank's time slice in mode "time", row chunks of the all-gather in mode "targets".
+# A keyword of the sharded_* functions (`chunks=`); the same on every rank.
+DEFAULT_CHUNKS = 2
 
 
 def _dist():
@@ -52,37 +55,87 @@ def _default_compute(X_all, targets, J, algo):
     return engine.mbd_counts_range(X_all, int(targets[0]), len(targets), J=J, algo=algo, return_tensor=True)
 
 
-def gather_curve_blocks(X_loc, group=None, sizes=None):
+def gather_curve_blocks(X_loc, group=None, sizes=None, rows=None, async_op=False):
     """All-gather of per-rank curve blocks.
 
     X_loc: [T, n_loc] time-major tensor (n_loc may differ between ranks).
     sizes: per-rank block sizes when the caller already knows the partition (skips the size exchange).
-    Returns (X_all [T, n] with rank blocks side by side, offsets [world+1]).
+    rows:  (lo, hi): only these timepoints of every block travel (the caller pipelines row chunks against the compute:
+           band totals are sums over timepoints, so each chunk is computed on as it arrives).
+    Returns (X_all [T or hi - lo, n] with rank blocks side by side, offsets [world+1]); with async_op=True
+    ((work, finish), offsets): `finish()` waits for the exchange (the current stream waits) and lays the rows out.
     """
     import torch
     dist = _dist()
     world = dist.get_world_size(group)
-    T, n_loc = X_loc.shape
     sizes = block_sizes(X_loc, group, sizes)
     offsets = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    if rows is not None:
+        X_loc = X_loc[int(rows[0]):int(rows[1])]
+    T, n_loc = X_loc.shape
     if min(sizes) == max(sizes):
         # equal blocks: gather the time-major blocks as they lie, then one strided copy lays the rows out
         recv = torch.empty((world * T, n_loc), dtype=X_loc.dtype, device=X_loc.device)
-        dist.all_gather_into_tensor(recv, X_loc.contiguous(), group=group)
-        X_all = torch.empty((T, world * n_loc), dtype=X_loc.dtype, device=X_loc.device)
-        X_all.view(T, world, n_loc).copy_(recv.view(world, T, n_loc).permute(1, 0, 2))
-        return X_all, offsets
-    nmax = max(sizes)
-    # blocks travel curve-major ([n_loc, T] rows are whole curves) so a ragged tail is plain padding
-    send = torch.zeros((nmax, T), dtype=X_loc.dtype, device=X_loc.device)
-    send[:n_loc].copy_(X_loc.t())
-    recv = torch.empty((world * nmax, T), dtype=X_loc.dtype, device=X_loc.device)
-    dist.all_gather_into_tensor(recv, send, group=group)
-    recv = recv.view(world, nmax, T)
-    X_all = torch.empty((T, int(offsets[-1])), dtype=X_loc.dtype, device=X_loc.device)
-    for r in range(world):
-        X_all[:, offsets[r]:offsets[r + 1]].copy_(recv[r, :sizes[r]].t())
-    return X_all, offsets
+        send = X_loc.contiguous()
+        work = dist.all_gather_into_tensor(recv, send, group=group, async_op=async_op)
+
+        def finish():
+            if work is not None:
+                work.wait()
+            X_all = torch.empty((T, world * n_loc), dtype=X_loc.dtype, device=X_loc.device)
+            X_all.view(T, world, n_loc).copy_(recv.view(world, T, n_loc).permute(1, 0, 2))
+            _ = send                                         # the send buffer lives as long as this closure
+            return X_all
+    else:
+        nmax = max(sizes)
+        # blocks travel curve-major ([n_loc, T] rows are whole curves) so a ragged tail is plain padding
+        send = torch.zeros((nmax, T), dtype=X_loc.dtype, device=X_loc.device)
+        send[:n_loc].copy_(X_loc.t())
+        recv = torch.empty((world * nmax, T), dtype=X_loc.dtype, device=X_loc.device)
+        work = dist.all_gather_into_tensor(recv, send, group=group, async_op=async_op)
+
+        def finish():
+            if work is not None:
+                work.wait()
+            rv = recv.view(world, nmax, T)
+            X_all = torch.empty((T, int(offsets[-1])), dtype=X_loc.dtype, device=X_loc.device)
+            for r in range(world):
+                X_all[:, offsets[r]:offsets[r + 1]].copy_(rv[r, :sizes[r]].t())
+            _ = send
+            return X_all
+    if async_op:
+        return (work, finish), offsets
+    return finish(), offsets
+
+
+def sharded_mbd_counts_targets(X_loc, J=2, algo="auto", group=None, sizes=None, _compute=None, chunks=None):
+    """Target-sharded totals (north_star's wording: all-gather of curve blocks, every rank computes its own targets), with the
+    all-gather cut into `chunks` row chunks: band totals are sums over timepoints, so chunk k is computed on (current stream)
+    while chunk k + 1 travels (RCCL's stream), and the partial totals add up.  Returns (int64 [n_loc, J-1], offsets)."""
+    import torch
+    dist = _dist()
+    rank = dist.get_rank(group)
+    sizes = block_sizes(X_loc, group, sizes)
+    T = int(X_loc.shape[0])
+    K = max(1, min(int(chunks if chunks is not None else DEFAULT_CHUNKS), max(T, 1)))
+    bounds = _chunk_bounds(T, K)
+    compute = _compute or _default_compute
+    total, offsets = None, None
+    pending, offsets = gather_curve_blocks(X_loc, group, sizes, rows=(bounds[0], bounds[1]), async_op=True)
+    for k in range(K):
+        nxt = gather_curve_blocks(X_loc, group, sizes, rows=(bounds[k + 1], bounds[k + 2]), async_op=True)[0] if k + 1 < K else None
+        X_all = pending[1]()
+        pending = nxt
+        if X_all.shape[0] == 0:
+            continue
+        targets = np.arange(offsets[rank], offsets[rank + 1], dtype=np.int64)
+        part = compute(X_all, targets, J, algo)
+        if not isinstance(part, torch.Tensor):
+            part = torch.as_tensor(np.asarray(part), device=X_loc.device)
+        total = part if total is None else total + part
+    if total is None:
+        total = torch.zeros((int(sizes[rank]), J - 1), dtype=torch.int64, device=X_loc.device)
+    return total, offsets
 
 
 def _time_slices(T, world):
@@ -190,7 +243,7 @@ def sharded_mbd_counts_time(X_loc, J=2, algo="auto", group=None, sizes=None, _co
     # the rows of sub-slice k are ranked (current stream).  K is the same on every rank: it depends on T and the
     # world size only.
     cnt, _ = _time_slices(T, world)
-    K = chunks if chunks is not None else int(os.environ.get("SD_DIST_CHUNKS", "2"))
+    K = int(chunks) if chunks is not None else DEFAULT_CHUNKS
     K = max(1, min(K, min(cnt)))
     part = None
     pending = exchange_to_time_slices(X_loc, sizes, group, 0, K, async_op=True)
@@ -214,8 +267,11 @@ def sharded_mbd_counts_time(X_loc, J=2, algo="auto", group=None, sizes=None, _co
     return part[offsets[rank]:offsets[rank + 1]].clone()
 
 
-# Measured single-GPU rates of the rank routes (keys ranked per second, MI355X) and of the pairwise
-# kernel (target x curve x timepoint triples per second); xGMI: one link per peer, ~50 GB/s per direction sustained.
+# The three constants of mode_cost_model, in one place.  UNVALIDATED BEYOND ONE GPU: the ranking rates are measured single-GPU
+# rates (keys ranked per second, MI355X) and so is the pairwise kernel's (target x curve x timepoint
+# triples per second); the link rate is an assumption (one xGMI link per peer, ~50 GB/s per direction sustained) that no run
+# on more than one GPU has met yet -- bench.py prints the model's predicted step beside the measured one (`mode` object of
+# its line) so that the first multi-GPU run calibrates them.
 _RANK_KEYS_PER_S = ((16384, 2.1e11), (32768, 1.0e11), (1 << 62, 9.4e10))
 _PAIR_TRIPLES_PER_S = 8.3e12
 _LINK_BYTES_PER_S = 50e9
@@ -248,12 +304,14 @@ def mode_cost_model(T, n_loc, world, J=2, algo="auto"):
 
 
 def sharded_mbd_counts(X_loc, J=2, algo="auto", group=None, gather_result=False, sizes=None, mode="auto",
-                       _compute=None, _compute_all=None, _force_exchange=False):
+                       _compute=None, _compute_all=None, _force_exchange=False, chunks=None):
     """MBD containment totals of this rank's curves against the union of all ranks' curves.
 
     mode: "targets" (all-gather of curve blocks, each rank computes its own targets: the pairwise
     kernel's natural split), "time" (all-to-all + reduce-scatter: the rank kernels' natural split, see
-    sharded_mbd_counts_time) or "auto" (time when J <= 3 and there are at least as many timepoints as ranks).
+    sharded_mbd_counts_time) or "auto" (the cheaper one by mode_cost_model; it needs the block sizes of all ranks: one small
+    all-gather with a host synchronisation per call unless the caller passes `sizes`).
+    chunks: pieces the exchange is cut into and pipelined against the compute (default DEFAULT_CHUNKS; the same on every rank).
 
     Returns int64 [n_loc, J-1] (device of X_loc), or with gather_result=True the full
     [n, J-1] array on every rank in global curve order.
@@ -272,15 +330,10 @@ def sharded_mbd_counts(X_loc, J=2, algo="auto", group=None, gather_result=False,
     if mode == "time":
         sizes = block_sizes(X_loc, group, sizes)
         local = sharded_mbd_counts_time(X_loc, J=J, algo=algo, group=group, sizes=sizes, _compute_all=_compute_all,
-                                        _force_exchange=_force_exchange)
+                                        _force_exchange=_force_exchange, chunks=chunks)
         offsets = np.concatenate([[0], np.cumsum([int(v) for v in sizes])]).astype(np.int64)
     else:
-        X_all, offsets = gather_curve_blocks(X_loc, group, sizes)
-        targets = np.arange(offsets[rank], offsets[rank + 1], dtype=np.int64)
-        compute = _compute or _default_compute
-        local = compute(X_all, targets, J, algo)
-        if not isinstance(local, torch.Tensor):
-            local = torch.as_tensor(np.asarray(local), device=X_loc.device)
+        local, offsets = sharded_mbd_counts_targets(X_loc, J=J, algo=algo, group=group, sizes=sizes, _compute=_compute, chunks=chunks)
     if not gather_result:
         return local
     sizes = np.diff(offsets)

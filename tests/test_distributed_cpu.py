@@ -61,10 +61,14 @@ def _worker(rank, world, port, splits, J, q):
         full_t = sharded_mbd_counts(X_loc, J=J, mode="auto", gather_result=True, **hooks)
         assert (loc_t == loc).all() and (full_t == full).all()
         # the exchange pipelined in 1, 3 and (more sub-slices than rows per rank) 50 pieces: same integers
-        for k in ("1", "3", "50"):
-            os.environ["SD_DIST_CHUNKS"] = k
-            assert (sharded_mbd_counts(X_loc, J=J, mode="time", **hooks) == loc).all(), k
-        os.environ.pop("SD_DIST_CHUNKS")
+        # (and the all-gather of the targets mode in row chunks, each computed on as it arrives: totals add over timepoints)
+        for k in (1, 3, 50):
+            assert (sharded_mbd_counts(X_loc, J=J, mode="time", chunks=k, **hooks) == loc).all(), k
+            assert (sharded_mbd_counts(X_loc, J=J, mode="targets", chunks=k, **hooks) == loc).all(), k
+        # a row range of the blocks, asynchronously: what the chunked targets mode is made of
+        from statdepth_amd.distributed import gather_curve_blocks
+        (work, finish), offs = gather_curve_blocks(X_loc, rows=(3, 11), async_op=True)
+        assert (finish().numpy() == X[3:11]).all() and list(offs) == list(splits)
         df = pd.DataFrame(X[:, lo:hi], columns=[f"c{i}" for i in range(lo, hi)])
         ser = sharded_functional_depth(df, J=J, relax=True, **hooks)
         # strict depth: targets split, all-gather of the blocks
@@ -211,3 +215,25 @@ def test_sharded_pointcloud_equals_single(splits):
         lo, hi = splits[rank], splits[rank + 1]
         assert (ex == want_ex[lo:hi]).all() and (sm == want_sm[lo:hi]).all()
         assert np.max(np.abs(l1 - want_l1[lo:hi])) <= 1e-12
+
+
+def test_mode_cost_model_choices_are_pinned():
+    """mode="auto" picks the collective pattern from mode_cost_model: the choice for representative shapes, and that it is a
+    function of what all ranks share (T, the largest block, the world size, J, algo) -- never of the calling rank."""
+    from statdepth_amd.distributed import mode_cost_model
+    # one GPU: no exchange either way, the time split never loses
+    assert mode_cost_model(1000, 10000, 1)["choice"] == "time"
+    # the rank kernels (J <= 3): splitting the timepoints divides the ranking, the all-gather split does all of it on every rank
+    for world in (2, 4, 8):
+        m = mode_cost_model(1000, 10000, world)
+        assert m["choice"] == "time" and m["time"] < m["targets"]
+        m = mode_cost_model(256, 12500, world)
+        assert m["choice"] == "time"
+    # fewer timepoints than ranks: nothing to split
+    assert mode_cost_model(3, 125000, 8)["choice"] == "targets"
+    # the pairwise kernel (asked for, or J >= 4): per-target work, the targets are what is split
+    assert mode_cost_model(1000, 10000, 8, algo="pairwise")["choice"] == "targets"
+    assert mode_cost_model(1000, 10000, 8, J=4)["choice"] == "targets"
+    # same arguments, same answer: the model holds no state and reads no rank
+    a, b = mode_cost_model(777, 4321, 4, 3), mode_cost_model(777, 4321, 4, 3)
+    assert a == b and set(a) >= {"time", "targets", "choice"}
