@@ -34,11 +34,11 @@ namespace sd {
 int launch_rank_bucket_image(const double *Y, i64 n, i64 row0, i64 rows, u32 *AB, u32 *nnan, hipStream_t s);   // mbd_rank_bucket.hip
 int launch_rank_medium_image(const double *Y, i64 n, i64 row0, i64 rows, u32 *AB, u32 *nnan, hipStream_t s);   // ... its two-block form
 int launch_rank_big_image(const double *Y, i64 T, i64 n, u32 *img, u32 *nnan, void *ws, size_t ws_bytes, hipStream_t s);   // mbd_rank_big.hip
-// bd_strict_grid.hip: three coordinates at large n through a grid of cells instead of every pair of points
+// bd_strict_grid.hip: two to four coordinates at large n through a grid of cells instead of every pair of points
 bool bd_strict_grid_applies(i64 T, i64 n, int J);
-size_t bd_strict_grid_workspace_bytes(i64 n, bool subset);
-int launch_bd_strict_grid(const double *Y, i64 n, const i64 *targets, i64 m, u64 *out, int jcols, u32 *flag, void *ws, size_t ws_bytes,
-                          hipStream_t s);
+size_t bd_strict_grid_workspace_bytes(i64 T, i64 n, bool subset);
+int launch_bd_strict_grid(const double *Y, i64 T, i64 n, const i64 *targets, i64 m, u64 *out, int jcols, u32 *flag, void *ws,
+                          size_t ws_bytes, hipStream_t s);
 // ... for all targets, or a subset that is not small (else the state-class kernel's O(m n) is less work)
 static inline bool strict_grid_wanted(i64 T, i64 n, i64 m, int J) {
     return bd_strict_grid_applies(T, n, J) && m * 32 >= n && xswitch("SD_STRICT_V1") != 1 && xswitch("SD_STRICT_NOCLASS") != 1 &&
@@ -110,7 +110,7 @@ static size_t strict_ws_for_batch(i64 T, i64 n, i64 b) {
 size_t bd_strict_workspace_bytes(i64 T, i64 n, i64 m, int J) {
     // short series go through the class kernel (launch_bd_strict_classes): a flag, no images -- three coordinates at large n
     // through the grid of cells (rank image, records in three orders, cell histogram, class counts)
-    if (strict_grid_wanted(T, n, m, J)) return bd_strict_grid_workspace_bytes(n, m < n) + 4096;
+    if (strict_grid_wanted(T, n, m, J)) return bd_strict_grid_workspace_bytes(T, n, m < n) + 4096;
     if (strict_class_applies(T, n, J) && xswitch("SD_STRICT_V1") != 1 && xswitch("SD_STRICT_NOCLASS") != 1) return 4096;
     // 6 ... 8 timepoints: the class kernel's flag in front of what the mask pipeline takes should the data hold NaN (beyond
     // the matching's reach there is no such fallback: the flag only)
@@ -1618,13 +1618,16 @@ int launch_bd_strict_classes(const double *Y, i64 T, i64 n, const i64 *targets, 
                        dim3(st_cl_threads(TT_, false)), 0, s, Y, n, targets, Q, m, (const u32 *)flag, out, jcols);             \
     hipLaunchKernelGGL((strict_class_kernel<TT_, true>), dim3((unsigned)((m + st_cl_threads(TT_, true) - 1) / st_cl_threads(TT_, true))),   \
                        dim3(st_cl_threads(TT_, true)), 0, s, Y, n, targets, Q, m, (const u32 *)flag, out, jcols);
-    // three coordinates at large n, external targets aside: the grid of cells (bd_strict_grid.hip) when the workspace holds it (a
+#define ST_CL_NAN(TT_)                                                                                                         \
+    hipLaunchKernelGGL((strict_class_kernel<TT_, true>), dim3((unsigned)((m + st_cl_threads(TT_, true) - 1) / st_cl_threads(TT_, true))),   \
+                       dim3(st_cl_threads(TT_, true)), 0, s, Y, n, targets, Q, m, (const u32 *)flag, out, jcols);
+    // two to four coordinates at large n, external targets aside: the grid of cells (bd_strict_grid.hip) when the workspace holds it (a
     // caller that passed the floor keeps the O(m n) kernels); it sets the flag itself from the rank route's NaN counts
-    if (T == 3 && !Q && strict_grid_wanted(T, n, m, 2) && ws_bytes >= bd_strict_grid_workspace_bytes(n, targets != nullptr)) {
-        int rc = launch_bd_strict_grid(Y, n, targets, m, out, jcols, flag, ws, ws_bytes, s);
+    if (!Q && strict_grid_wanted(T, n, m, 2) && ws_bytes >= bd_strict_grid_workspace_bytes(T, n, targets != nullptr)) {
+        int rc = launch_bd_strict_grid(Y, T, n, targets, m, out, jcols, flag, ws, ws_bytes, s);
         if (rc) return rc;
-        hipLaunchKernelGGL((strict_class_kernel<3, true>), dim3((unsigned)((m + st_cl_threads(3, true) - 1) / st_cl_threads(3, true))),
-                           dim3(st_cl_threads(3, true)), 0, s, Y, n, targets, Q, m, (const u32 *)flag, out, jcols);
+        // data with NaN (the flag is set): the four-state lane kernel, which returns at once otherwise
+        if (T == 2) { ST_CL_NAN(2) } else if (T == 3) { ST_CL_NAN(3) } else { ST_CL_NAN(4) }
         SD_HIP(hipGetLastError());
         return SD_OK;
     }
@@ -1656,6 +1659,7 @@ int launch_bd_strict_classes(const double *Y, i64 T, i64 n, const i64 *targets, 
         default: return fail(SD_ERR_UNSUPPORTED, "the class kernel covers up to five timepoints");
     }
 #undef ST_CL_LAUNCH
+#undef ST_CL_NAN
     SD_HIP(hipGetLastError());
     return SD_OK;
 }

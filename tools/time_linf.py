@@ -10,8 +10,9 @@ torch.cuda.init()
 from statdepth_amd import engine, _native
 PRODUCT = _native.load()
 XCHECK = _native.open_library(_native.XCHECK_LIB_PATH)
+D = int(os.environ.get("SD_D", "3"))
 for n in [int(a) for a in sys.argv[1:]] or [100000, 300000, 1000000]:
-    P = np.random.default_rng(1237).normal(size=(n, 3))
+    P = np.random.default_rng(1237).normal(size=(n, D))
     if os.environ.get("SD_KIND") == "ties":
         P = np.round(P, 1)
     X = torch.from_numpy(np.ascontiguousarray(P.T)).cuda()
