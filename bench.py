@@ -265,8 +265,10 @@ def extras_single_gpu(torch, dev, stream, lib, check, ALGOS, oracle, reps=10):
     out["l1_1e5x3"] = {"workload": "L1 depth, 10^5 points in R^3", "ms": ms, "point_pairs_per_s": 1e10 / (ms * 1e-3),
                        "checked_targets": len(tg)}
     oc = torch.empty(100000, dtype=torch.int64, device=dev)
+    wss = int(lib.sd_simplex_sampled_workspace_bytes(100000, 0, 3, 256))
+    wsx = torch.empty(max(wss, 8), dtype=torch.uint8, device=dev)
     _, ms = timed(lambda _: check(lib.sd_pointcloud_simplex_sampled(Pd.data_ptr(), 100000, 3, 0, 100000, 1e-7, 256, 1237,
-                                                                   oc.data_ptr(), stream.cuda_stream)), 3, 1, stream, torch)
+                                                                   oc.data_ptr(), wsx.data_ptr(), wss, stream.cuda_stream)), 3, 1, stream, torch)
     tg = np.arange(0, 100000, 500)
     assert (oc.cpu().numpy()[tg] == oracle.simplex_sampled(P, tg, samples=256, seed=1237)).all(), "simplex d=3"
     out["simplex_sampled_d3"] = {"workload": "10^5 points in R^3, 256 tetrahedra per point", "ms": ms,
@@ -275,8 +277,11 @@ def extras_single_gpu(torch, dev, stream, lib, check, ALGOS, oracle, reps=10):
     C[:8] *= 0.02
     Cd = torch.from_numpy(C).to(dev)
     oc = torch.empty(500, dtype=torch.int64, device=dev)
+    wss = int(lib.sd_simplex_sampled_workspace_bytes(500, 50, 8, 256))
+    wsx = torch.empty(max(wss, 8), dtype=torch.uint8, device=dev)
     _, ms = timed(lambda _: check(lib.sd_multi_simplex_sampled(Cd.data_ptr(), 500, 50, 8, 0, 500, 1, 1e-7, 256, 1236,
-                                                              oc.data_ptr(), stream.cuda_stream)), 3, 1, stream, torch)
+                                                              oc.data_ptr(), wsx.data_ptr(), wss, stream.cuda_stream)), 3, 1, stream, torch)
+    del wsx
     tg = np.arange(0, 500, 31)
     assert (oc.cpu().numpy()[tg] == oracle.simplex_sampled(C, tg, relax=True, samples=256, seed=1236)).all(), "simplex d=8"
     out["simplex_sampled_d8"] = {"workload": "500 curves x 50 timepoints x 8 features, 256 subsets per target (config 4 shape)",
@@ -332,8 +337,10 @@ def extras_full_size_configs(torch, dev, stream, lib, check, oracle):
     g = torch.Generator(device=dev).manual_seed(1236)
     C4 = torch.randn(n4, T4, d4, dtype=torch.float64, device=dev, generator=g).cumsum(1)
     o4 = torch.empty(n4, dtype=torch.int64, device=dev)
+    wss = int(lib.sd_simplex_sampled_workspace_bytes(n4, T4, d4, S4))
+    wsx = torch.empty(max(wss, 8), dtype=torch.uint8, device=dev)
     _, ms = timed(lambda _: check(lib.sd_multi_simplex_sampled(C4.data_ptr(), n4, T4, d4, 0, n4, 1, 1e-7, S4, 1236, o4.data_ptr(),
-                                                              stream.cuda_stream)), 1, 0, stream, torch)
+                                                              wsx.data_ptr(), wss, stream.cuda_stream)), 1, 1, stream, torch)
     tg = np.array([0, 2500, 4999])
     assert (o4.cpu().numpy()[tg] == oracle.simplex_sampled(C4.cpu().numpy(), tg, relax=True, samples=S4, seed=1236)).all(), "config 4"
     units = float(n4) * S4 * T4
@@ -341,7 +348,7 @@ def extras_full_size_configs(torch, dev, stream, lib, check, oracle):
         "workload": "config 4 (i): 5000 curves x 500 timepoints x 8 features, 4096 sampled subsets per target (seed 1236), relax=True",
         "ms": ms, "simplex_tests_per_s": units / (ms * 1e-3), "checked_targets": len(tg),
         "roofline": issue_roofline("simplex8", units / (ms * 1e-3))}
-    del C4, o4
+    del C4, o4, wsx
     # ---- config 5 (ii) L1 depth and (iii) 4 096 sampled tetrahedra per point, 10^6 points in R^3
     n5 = 1000000
     P5 = np.random.default_rng(1237).normal(size=(n5, 3))
@@ -355,8 +362,10 @@ def extras_full_size_configs(torch, dev, stream, lib, check, oracle):
                               "point_pairs_per_s": units / (ms * 1e-3), "checked_targets": len(tg),
                               "roofline": issue_roofline("l1", units / (ms * 1e-3))}
     oc = torch.empty(n5, dtype=torch.int64, device=dev)
+    wss = int(lib.sd_simplex_sampled_workspace_bytes(n5, 0, 3, 4096))
+    wsx = torch.empty(max(wss, 8), dtype=torch.uint8, device=dev)
     _, ms = timed(lambda _: check(lib.sd_pointcloud_simplex_sampled(Pd.data_ptr(), n5, 3, 0, n5, 1e-7, 4096, 1237, oc.data_ptr(),
-                                                                   stream.cuda_stream)), 2, 1, stream, torch)
+                                                                   wsx.data_ptr(), wss, stream.cuda_stream)), 2, 1, stream, torch)
     tg = np.arange(0, n5, 10000)
     assert (oc.cpu().numpy()[tg] == oracle.simplex_sampled(P5, tg, samples=4096, seed=1237)).all(), "config 5 simplex"
     units = float(n5) * 4096

@@ -248,16 +248,24 @@ int sd_pointcloud_simplex_subset_counts(const double *P, int64_t n, int d, const
 /* Seeded uniform subset-sampling estimators for sizes where exhaustive
  * enumeration is impossible (BASELINE.json configs 4 and 5; not in the
  * reference).  For each target, `samples` (d+1)-subsets of the
- * other items are drawn with a counter-based generator keyed by
- * (seed, target index, sample number); out[q] = number of containing simplices
- * (pointcloud) or sum over samples of c / [c == T] (multi).
+ * other items are drawn with a counter-based generator (keys below); out[q] = number of
+ * containing simplices (pointcloud) or sum over samples of c / [c == T] (multi).
  */
+/* Round 4: sample s is ONE (d+1)-subset of all n items for every target (generator keyed by (seed, s)); a target that is
+ * itself a member gets that member replaced by an item drawn with the generator keyed by (seed, target, s) -- every target
+ * sees `samples` uniform subsets of the other items, and the subset's elimination is shared by all targets (each target only
+ * carries its right-hand side through the recorded row operations: the same barycentric coordinates bit for bit).
+ * ws / ws_bytes: optional (NULL / 0 allowed) records of a batch of (timepoint, sample) pairs, sd_simplex_sampled_workspace_bytes;
+ * with it the factorisation and the replay are two kernels (d >= 4: several times faster), without it one. */
+size_t sd_simplex_sampled_workspace_bytes(int64_t n, int64_t T, int d, int64_t samples);
 int sd_pointcloud_simplex_sampled(const double *P, int64_t n, int d,
                                   const int64_t *targets, int64_t m, double tol,
-                                  int64_t samples, uint64_t seed, int64_t *out, void *stream);
+                                  int64_t samples, uint64_t seed, int64_t *out,
+                                  void *ws, size_t ws_bytes, void *stream);
 int sd_multi_simplex_sampled(const double *P, int64_t n, int64_t T, int d,
                              const int64_t *targets, int64_t m, int relax, double tol,
-                             int64_t samples, uint64_t seed, int64_t *out, void *stream);
+                             int64_t samples, uint64_t seed, int64_t *out,
+                             void *ws, size_t ws_bytes, void *stream);
 
 /* ---- K6: componentwise band containment of multivariate curves ('r2_enum') --------
  * Fills: _r2_enum_containment (_containment.py:83-103), which the reference declares -- "treat each component in the

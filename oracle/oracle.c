@@ -575,8 +575,8 @@ int oracle_multi_simplex_counts(const double *P, long n, long T, int d, const lo
 /* --------------------------------------------------------------------------
  * Seeded subset-sampling estimators (BASELINE.json configs 4 and 5; NOT in the reference, which can only
  * enumerate).  The sampler is the build's own definition, restated here so that the HIP kernels
- * (csrc/simplex.hip: sample_subset) can be checked draw for draw: splitmix64 counter generator keyed by
- * (seed, target, sample); k distinct indices in [0, no) by rejection, sorted ascending.
+ * (csrc/simplex.hip: sample_subset) can be checked draw for draw: splitmix64 counter generator, k distinct rows by
+ * rejection, sorted ascending (see sample_rows below for the keys).
  * -------------------------------------------------------------------------- */
 static u64 mix64(u64 z) {
     z += 0x9E3779B97F4A7C15ull;
@@ -585,12 +585,16 @@ static u64 mix64(u64 z) {
     return z ^ (z >> 31);
 }
 
-static void sample_subset(u64 seed, u64 tg, u64 sample, int k, long no, long *idx) {
-    u64 key = mix64(seed ^ mix64(tg * 0xD1342543DE82EF95ull + sample));
+/* Round 4: shared sample s is ONE (d+1)-subset of all n rows for every target (generator keyed by (seed, s)), so that the
+ * HIP kernels can share its factorisation between the targets; a target uses the FIRST `samples` shared subsets that do not
+ * contain it (s = 0, 1, 2, ... in order): each is uniform over the subsets of the other rows. */
+#define SX_SHARED_KEY 0xFFFFFFFFFFFFFFFFull
+static void sample_rows(u64 seed, u64 keyv, u64 sample, int k, long n, long *idx) {
+    u64 key = mix64(seed ^ mix64(keyv * 0xD1342543DE82EF95ull + sample));
     u64 ctr = 0;
     for (int p = 0; p < k;) {
         u64 r = mix64(key + ctr++);
-        long c = (long)(((unsigned __int128)r * (unsigned __int128)(u64)no) >> 64);   /* floor(r * no / 2^64) */
+        long c = (long)(((unsigned __int128)r * (unsigned __int128)(u64)n) >> 64);   /* floor(r * n / 2^64) */
         int dup = 0;
         for (int l = 0; l < p; ++l) dup |= (idx[l] == c);
         if (!dup) idx[p++] = c;
@@ -600,6 +604,16 @@ static void sample_subset(u64 seed, u64 tg, u64 sample, int k, long no, long *id
         int b = a - 1;
         while (b >= 0 && idx[b] > v) { idx[b + 1] = idx[b]; --b; }
         idx[b + 1] = v;
+    }
+}
+
+/* the next shared subset from index *s on that does not contain row tg; *s is left behind it */
+static void sample_next_valid(u64 seed, long tg, u64 *s, int k, long n, long *idx) {
+    for (;;) {
+        sample_rows(seed, SX_SHARED_KEY, (*s)++, k, n, idx);
+        int member = 0;
+        for (int l = 0; l < k; ++l) member |= idx[l] == tg;
+        if (!member) return;
     }
 }
 
@@ -615,12 +629,13 @@ int oracle_simplex_sampled(const double *P, long n, long T, int d, const long *t
         i64 S = 0;
         long idx[SMAX];
         double pts[SMAX * SMAX];
+        u64 snext = 0;
         for (long s = 0; s < samples; ++s) {
-            sample_subset(seed, (u64)tg, (u64)s, k, n - 1, idx);
+            sample_next_valid(seed, tg, &snext, k, n, idx);
             long cnt = 0;
             for (long t = 0; t < T; ++t) {
                 for (int c = 0; c < k; ++c) {
-                    long src = idx[c] < tg ? idx[c] : idx[c] + 1;
+                    long src = idx[c];                              /* rows, never the target's */
                     memcpy(pts + c * d, P + (src * T + t) * d, sizeof(double) * d);
                 }
                 cnt += oracle_point_in_hull(pts, k, d, P + (tg * T + t) * d, tol) > 0;

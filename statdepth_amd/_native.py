@@ -61,10 +61,11 @@ SIGNATURES = {
     "sd_pointcloud_simplex_subset_counts": (_int, [_vp, _i64, _int, _vp, _i64, _int, _dbl, _vp, _vp]),
     "sd_pointcloud_simplex_counts": (_int, [_vp, _i64, _int, _vp, _i64, _dbl, _vp, _vp]),
     "sd_multi_simplex_counts": (_int, [_vp, _i64, _i64, _int, _vp, _i64, _int, _dbl, _vp, _vp]),
-    "sd_pointcloud_simplex_sampled": (_int, [_vp, _i64, _int, _vp, _i64, _dbl, _i64, _u64, _vp, _vp]),
+    "sd_simplex_sampled_workspace_bytes": (_sz, [_i64, _i64, _int, _i64]),
+    "sd_pointcloud_simplex_sampled": (_int, [_vp, _i64, _int, _vp, _i64, _dbl, _i64, _u64, _vp, _vp, _sz, _vp]),
     "sd_multi_band_workspace_bytes": (_sz, [_i64, _i64, _int]),
     "sd_multi_band_counts": (_int, [_vp, _i64, _i64, _int, _vp, _i64, _vp, _vp, _sz, _vp]),
-    "sd_multi_simplex_sampled": (_int, [_vp, _i64, _i64, _int, _vp, _i64, _int, _dbl, _i64, _u64, _vp, _vp]),
+    "sd_multi_simplex_sampled": (_int, [_vp, _i64, _i64, _int, _vp, _i64, _int, _dbl, _i64, _u64, _vp, _vp, _sz, _vp]),
 }
 
 

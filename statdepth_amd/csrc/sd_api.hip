@@ -481,14 +481,19 @@ int sd_pointcloud_simplex_counts(const double *P, int64_t n, int d, const int64_
     return launch_pointcloud_simplex(P, n, d, targets, m, tol, -1, 0, (u64 *)out, (hipStream_t)stream);
 }
 
+size_t sd_simplex_sampled_workspace_bytes(int64_t n, int64_t T, int d, int64_t samples) {
+    return simplex_sampled_workspace_bytes(n, T, d, samples);
+}
+
 int sd_pointcloud_simplex_sampled(const double *P, int64_t n, int d, const int64_t *targets, int64_t m,
-                                  double tol, int64_t samples, uint64_t seed, int64_t *out, void *stream) {
+                                  double tol, int64_t samples, uint64_t seed, int64_t *out, void *ws, size_t ws_bytes,
+                                  void *stream) {
     int rc = check_simplex(P, n, d, targets, m, out, false, n - 1);
     if (rc) return rc;
     if (samples <= 0) return fail(SD_ERR_INVALID, "samples must be positive");
     if (n - 1 < d + 1) return fail(SD_ERR_INVALID, "need at least d+2 points");
     if (m == 0) return SD_OK;
-    return launch_pointcloud_simplex(P, n, d, targets, m, tol, samples, seed, (u64 *)out, (hipStream_t)stream);
+    return launch_pointcloud_simplex(P, n, d, targets, m, tol, samples, seed, (u64 *)out, (hipStream_t)stream, ws, ws_bytes);
 }
 
 int sd_pointcloud_simplex_external_counts(const double *P, int64_t n, int d, const double *Q, int64_t m, double tol,
@@ -542,14 +547,15 @@ int sd_multi_band_counts(const double *P, int64_t n, int64_t T, int d, const int
 }
 
 int sd_multi_simplex_sampled(const double *P, int64_t n, int64_t T, int d, const int64_t *targets, int64_t m,
-                             int relax, double tol, int64_t samples, uint64_t seed, int64_t *out, void *stream) {
+                             int relax, double tol, int64_t samples, uint64_t seed, int64_t *out, void *ws, size_t ws_bytes,
+                             void *stream) {
     int rc = check_simplex(P, n, d, targets, m, out, false, n - 1);
     if (rc) return rc;
     if (T <= 0) return fail(SD_ERR_INVALID, "T <= 0");
     if (samples <= 0) return fail(SD_ERR_INVALID, "samples must be positive");
     if (n - 1 < d + 1) return fail(SD_ERR_INVALID, "need at least d+2 curves");
     if (m == 0) return SD_OK;
-    return launch_multi_simplex(P, n, T, d, targets, m, relax, tol, samples, seed, (u64 *)out, (hipStream_t)stream);
+    return launch_multi_simplex(P, n, T, d, targets, m, relax, tol, samples, seed, (u64 *)out, (hipStream_t)stream, ws, ws_bytes);
 }
 
 }  // extern "C"

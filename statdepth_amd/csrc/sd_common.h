@@ -106,9 +106,11 @@ int launch_pointcloud_simplex_external(const double *P, i64 n, int d, const doub
 int launch_pointcloud_simplex_subsets(const double *P, i64 n, int d, const int *members, i64 nb, int bs, double tol,
                                       u64 *out, hipStream_t s);
 int launch_pointcloud_simplex(const double *P, i64 n, int d, const i64 *targets, i64 m, double tol,
-                              i64 samples, u64 seed, u64 *out, hipStream_t s);
+                              i64 samples, u64 seed, u64 *out, hipStream_t s, void *ws = nullptr, size_t ws_bytes = 0);
 int launch_multi_simplex(const double *P, i64 n, i64 T, int d, const i64 *targets, i64 m, int relax,
-                         double tol, i64 samples, u64 seed, u64 *out, hipStream_t s);
+                         double tol, i64 samples, u64 seed, u64 *out, hipStream_t s, void *ws = nullptr, size_t ws_bytes = 0);
+// records of the sampled estimators' shared factorisation (a batch of (timepoint, sample) pairs)
+size_t simplex_sampled_workspace_bytes(i64 n, i64 T, int d, i64 samples);
 
 // K6 componentwise band containment of multivariate curves (band_enum.hip)
 bool multi_band_supported(i64 n, i64 T, int d);

@@ -149,16 +149,20 @@ __device__ __host__ static inline u64 mix64(u64 z) {
     return z ^ (z >> 31);
 }
 
-// draw k distinct indices in [0,no) for (seed, tg, sample): index = floor(r * no / 2^64), rejection on duplicates,
-// result sorted ascending.  Restated identically in oracle.c (oracle_sample_subset).
-__device__ static void sample_subset(u64 seed, u64 tg, u64 sample, int k, i64 no, i64 *idx) {
-    u64 key = mix64(seed ^ mix64(tg * 0xD1342543DE82EF95ull + sample));
+// The sampled estimators' subsets (round 4): shared sample s is ONE (d+1)-subset of all n rows for every target -- k distinct rows
+// drawn with the counter generator keyed by (seed, s): index = floor(r * n / 2^64), rejection on duplicates, sorted ascending -- so
+// that its factorisation can be shared by all targets (sxw_factor_kernel / sxw_apply_kernel).  A target uses the FIRST `samples`
+// shared subsets that do not contain it (s = 0, 1, 2, ... in order): each is uniform over the subsets of the other rows.
+// Restated identically in oracle.c (sample_rows / oracle_simplex_sampled).
+constexpr u64 SX_SHARED_KEY = 0xFFFFFFFFFFFFFFFFull;
+__device__ static void sample_rows(u64 seed, u64 keyv, u64 sample, int k, i64 n, i64 *idx) {
+    u64 key = mix64(seed ^ mix64(keyv * 0xD1342543DE82EF95ull + sample));
     u64 ctr = 0;
     for (int p = 0; p < k;) {
         u64 r = mix64(key + ctr++);
-        // index in [0, no) as the high half of r * no (a 64 x 64 -> 128 bit product: a handful of instructions; the 64-bit
+        // index in [0, n) as the high half of r * n (a 64 x 64 -> 128 bit product: a handful of instructions; the 64-bit
         // modulo it replaces was ~480 of the 715 lane-instructions of a sampled 4-point test, profiles/r02_issue_roofline.json)
-        i64 c = (i64)__umul64hi(r, (u64)no);
+        i64 c = (i64)__umul64hi(r, (u64)n);
         bool dup = false;
         for (int l = 0; l < p; ++l) dup |= (idx[l] == c);
         if (!dup) idx[p++] = c;
@@ -168,6 +172,15 @@ __device__ static void sample_subset(u64 seed, u64 tg, u64 sample, int k, i64 no
         int b = a - 1;
         while (b >= 0 && idx[b] > v) { idx[b + 1] = idx[b]; --b; }
         idx[b + 1] = v;
+    }
+}
+// the next shared subset from index *s on that does not contain row tg; *s is left behind it
+__device__ static void sample_next_valid(u64 seed, i64 tg, u64 *s, int k, i64 n, i64 *idx) {
+    for (;;) {
+        sample_rows(seed, SX_SHARED_KEY, (*s)++, k, n, idx);
+        bool member = false;
+        for (int l = 0; l < k; ++l) member |= idx[l] == tg;
+        if (!member) return;
     }
 }
 
@@ -229,9 +242,9 @@ __device__ __forceinline__ SxBlock sx_block(const SxSel &sel, const i64 *targets
     return b;
 }
 
-__device__ __forceinline__ i64 sx_src(const SxBlock &b, i64 i) {
+__device__ __forceinline__ i64 sx_src(const SxBlock &b, i64 i, bool sampled = false) {
     if (b.mem) return b.mem[i];
-    if (b.xq) return i;
+    if (b.xq || sampled) return i;                               // (a sampled subset holds rows, never the target's)
     return i < b.tg ? i : i + 1;                                 // skip the target itself
 }
 
@@ -254,13 +267,16 @@ __global__ __launch_bounds__(SX_THREADS) void simplex_kernel(
         i64 idx[SMAX];
         double pts[SMAX * 8], x[8];
         if (samples < 0) unrank_comb(first, k, no, idx);
+        u64 snext = 0;                                                  // sampled: the shared index behind the last subset taken
+        if (samples >= 0)
+            for (u64 r = 0; r < first; ++r) sample_next_valid(seed, tg, &snext, k, n, idx);   // this thread's first valid subset
         i64 TT = T > 0 ? T : 1;
         for (u64 r = first; r < last; ++r) {
-            if (samples >= 0) sample_subset(seed, blk.key, r, k, no, idx);
+            if (samples >= 0) sample_next_valid(seed, tg, &snext, k, n, idx);
             u64 cnt = 0;
             for (i64 t = 0; t < TT; ++t) {
                 for (int c = 0; c < k; ++c) {
-                    i64 src = sx_src(blk, idx[c]);
+                    i64 src = sx_src(blk, idx[c], samples >= 0);
                     const double *pp = P + (src * TT + t) * d;
                     for (int e = 0; e < d; ++e) pts[c * d + e] = pp[e];
                 }
@@ -399,9 +415,12 @@ __global__ __launch_bounds__(SX_THREADS) void simplex_kernel_fast(
         const u64 last = first + per_thread < total ? first + per_thread : total;
         i64 idx[SMAX];
         if (samples < 0) unrank_comb(first, K, no, idx);
+        u64 snext = 0;                                                  // sampled: the shared index behind the last subset taken
+        if (samples >= 0)
+            for (u64 r = 0; r < first; ++r) sample_next_valid(seed, tg, &snext, K, n, idx);   // this thread's first valid subset
         const i64 TT = T > 0 ? T : 1;
         for (u64 r = first; r < last; ++r) {
-            if (samples >= 0) sample_subset(seed, blk.key, r, K, no, idx);
+            if (samples >= 0) sample_next_valid(seed, tg, &snext, K, n, idx);
             u64 cnt = 0;
             for (i64 t = 0; t < TT; ++t) {
                 double R[K][K + 1];
@@ -410,7 +429,7 @@ __global__ __launch_bounds__(SX_THREADS) void simplex_kernel_fast(
                 const double *xx = blk.xq ? blk.xq : P + (tg * TT + t) * D;
 #pragma unroll
                 for (int c = 0; c < K; ++c) {
-                    const i64 src = sx_src(blk, idx[c]);
+                    const i64 src = sx_src(blk, idx[c], samples >= 0);
                     const double *pp = P + (src * TT + t) * D;
 #pragma unroll
                     for (int e = 0; e < D; ++e) {
@@ -433,7 +452,7 @@ __global__ __launch_bounds__(SX_THREADS) void simplex_kernel_fast(
                 if (res == 2) {                                         // degenerate simplex: generic code, from the data
                     double pts[SMAX * 8], x[8];
                     for (int c = 0; c < K; ++c) {
-                        const i64 src = sx_src(blk, idx[c]);
+                        const i64 src = sx_src(blk, idx[c], samples >= 0);
                         const double *pp = P + (src * TT + t) * D;
                         for (int e = 0; e < D; ++e) pts[c * D + e] = pp[e];
                     }
@@ -451,9 +470,442 @@ __global__ __launch_bounds__(SX_THREADS) void simplex_kernel_fast(
 }
 
 
+// ---------------------------------------------------------------------------------------------------
+// Sampled estimators, every target's sample s the SAME subset (sample_rows above): the subset's matrix [P_S^T; 1] is
+// eliminated ONCE and every target only carries its right-hand side [x; 1] through the recorded row operations.
+// point_in_hull() / solve_subset() touch the right-hand side in a fixed sequence of operations that depends on the matrix
+// alone -- the row exchanges of the complete-pivoting elimination, b_r -= f b_k for its multipliers f (skipped where f = 0),
+// the second (partial-pivoting) elimination of solve_subset on the triangular system with its own multipliers, the back
+// substitution -- so replaying that sequence gives the barycentric coordinates of the per-target elimination BIT FOR BIT,
+// at about 2 K^2 multiply-subtracts + K divisions per test instead of a K x K elimination (d = 8: ~400 instructions
+// against ~7 500; d = 3: ~90 against ~700, and no random gathers: the members are read once per subset).
+// What depends on the target besides the right-hand side is `scale` (it includes |x|) through rank_eps = 1e-10 scale: a
+// target whose own scale would put the smallest pivot at or below rank_eps, and a subset that is rank deficient, holds a NaN
+// or an infinity, or exchanges rows in the second elimination, take the per-target code (point_in_hull), decision for decision
+// the old kernel's.  A target that is a MEMBER of the subset skips it and takes a spare shared subset instead (the first
+// `samples` shared subsets that do not contain it: sxw_members_kernel counts what it skips, sxw_spare_kernel makes it up).
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double scw_u(double v) {                    // a wave-uniform double into SGPRs
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    const u32 lo = (u32)__builtin_amdgcn_readfirstlane((int)(u32)b), hi = (u32)__builtin_amdgcn_readfirstlane((int)(u32)(b >> 32));
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Two kernels over a caller's workspace (sd_simplex_sampled_workspace_bytes): the records go to HBM, a thread per (timepoint,
+// sample) with the whole register file for its elimination, and the replay reads a record as one coalesced load per wave.
+// Batches of pairs as large as the workspace holds.  Without a workspace the per-target kernels run (same subsets).
+// ---------------------------------------------------------------------------------------------------
+// the per-target code for a target the shared replay cannot serve (see above): out of line, so that its scratch arrays and
+// registers are not the replay loop's
+template <int D>
+__device__ __noinline__ int sxw_special(const double *P, i64 TT, i64 t, const int *mem, const double *xv, double tol) {
+    constexpr int K = D + 1;
+    double pts[SMAX * 8], x[8];
+    for (int c = 0; c < K; ++c) {
+        const double *pp = P + ((i64)mem[c] * TT + t) * D;
+        for (int e = 0; e < D; ++e) pts[c * D + e] = pp[e];
+    }
+    for (int e = 0; e < D; ++e) x[e] = xv[e];
+    return point_in_hull(pts, K, D, x, tol) ? 1 : 0;
+}
+
+template <int D> struct SxwCfg {
+    static constexpr int K = D + 1, NL = K * (K - 1) / 2, NU = K * (K + 1) / 2;
+    static constexpr int DW = 2 * NL + NU + 2;                          // doubles: f1, f2, u, scale, minpiv
+    static constexpr int IW = ((2 * K + 1 + 3) / 4) * 4;                // ints: perm, members, status; padded to 16 bytes
+    static constexpr size_t REC = (size_t)DW * 8 + (size_t)IW * 4;      // bytes of a record
+    static constexpr int TPT = D >= 5 ? 2 : 4;                          // targets per thread of the replay
+};
+
+// pairs [w0, w0 + cnt) of the call, pair w = timepoint w / samples, sample w % samples; one thread each
+template <int D>
+__global__ __launch_bounds__(64) void sxw_factor_kernel(const double *__restrict__ P, i64 n, i64 T, i64 samples, u64 seed, i64 w0, i64 cnt,
+                                                        double *__restrict__ recd, int *__restrict__ reci, double *__restrict__ m1g) {
+    using C = SxwCfg<D>;
+    constexpr int K = C::K, NL = C::NL, NU = C::NU, DW = C::DW, IW = C::IW;
+    const i64 v = (i64)blockIdx.x * 64 + threadIdx.x;
+    if (v >= cnt) return;
+    const i64 TT = T > 0 ? T : 1;
+    const i64 t = (w0 + v) / samples, sidx = (w0 + v) % samples;
+    i64 idx[K];
+    sample_rows(seed, SX_SHARED_KEY, (u64)sidx, K, n, idx);
+    double *rd = recd + (size_t)v * DW;
+    int *ri = reci + (size_t)v * IW;
+    double *m1l = m1g + (size_t)v * (K * (K - 1));                      // the first elimination's multipliers by ORIGINAL row
+    double R[K][K];
+    int rowid[K];
+    double scale = 1.0;
+    bool irregular = false;
+#pragma unroll
+    for (int c = 0; c < K; ++c) {
+        const double *pp = P + (idx[c] * TT + t) * D;
+#pragma unroll
+        for (int e = 0; e < D; ++e) {
+            const double x = pp[e];
+            irregular |= x != x;
+            R[e][c] = x;
+            scale = fabs(x) > scale ? fabs(x) : scale;
+        }
+        R[D][c] = 1.0;
+    }
+#pragma unroll
+    for (int i = 0; i < K; ++i) rowid[i] = i;
+    irregular |= isinf(scale);
+    const double rank_eps = 1e-10 * scale;
+    double minpiv = __builtin_huge_val();
+#pragma unroll
+    for (int rank = 0; rank < K; ++rank) {
+        int pr = -1, pc = -1;
+        double best = rank_eps;
+#pragma unroll
+        for (int r = rank; r < K; ++r)
+#pragma unroll
+            for (int c = rank; c < K; ++c) {
+                const double av = fabs(R[r][c]);
+                const bool gt = av > best;
+                best = gt ? av : best;
+                pr = gt ? r : pr;
+                pc = gt ? c : pc;
+            }
+        irregular |= pr < 0;                                            // rank deficient: the per-target code's business
+        minpiv = best < minpiv ? best : minpiv;
+#pragma unroll
+        for (int rr = rank + 1; rr < K; ++rr) {                         // exchange rows rank <-> pr
+            const bool sw = pr == rr;
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const double x0 = R[rank][k], x1 = R[rr][k];
+                R[rank][k] = sw ? x1 : x0;
+                R[rr][k] = sw ? x0 : x1;
+            }
+            const int i0 = rowid[rank], i1 = rowid[rr];
+            rowid[rank] = sw ? i1 : i0;
+            rowid[rr] = sw ? i0 : i1;
+        }
+#pragma unroll
+        for (int cc = rank + 1; cc < K; ++cc) {                         // exchange columns rank <-> pc
+            const bool sw = pc == cc;
+#pragma unroll
+            for (int r = 0; r < K; ++r) {
+                const double x0 = R[r][rank], x1 = R[r][cc];
+                R[r][rank] = sw ? x1 : x0;
+                R[r][cc] = sw ? x0 : x1;
+            }
+        }
+#pragma unroll
+        for (int r = rank + 1; r < K; ++r) {
+            const double f = R[r][rank] / R[rank][rank];
+            if (rank < K - 1) m1l[rowid[r] * (K - 1) + rank] = f;
+            const bool nz = f != 0.0;
+#pragma unroll
+            for (int c = rank; c < K; ++c) {
+                const double x = R[r][c] - f * R[rank][c];
+                R[r][c] = nz ? x : R[r][c];
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < K; ++c) {
+        const double best = fabs(R[c][c]);
+#pragma unroll
+        for (int r = c + 1; r < K; ++r) irregular |= fabs(R[r][c]) > best;
+        minpiv = best < minpiv ? best : minpiv;
+#pragma unroll
+        for (int r = c + 1; r < K; ++r) {
+            const double f = R[r][c] / R[c][c];
+            rd[NL + r * (r - 1) / 2 + c] = f;
+#pragma unroll
+            for (int k = c; k < K; ++k) R[r][k] -= f * R[c][k];
+        }
+    }
+    __threadfence_block();                                              // this thread's own multipliers, read back by row below
+#pragma unroll
+    for (int i = 1; i < K; ++i)
+#pragma unroll
+        for (int k = 0; k < i; ++k) rd[i * (i - 1) / 2 + k] = m1l[rowid[i] * (K - 1) + k];
+    {
+        int w = 0;
+#pragma unroll
+        for (int c = 0; c < K; ++c)
+#pragma unroll
+            for (int k = c; k < K; ++k) rd[2 * NL + w++] = R[c][k];
+    }
+    rd[2 * NL + NU] = scale;
+    rd[2 * NL + NU + 1] = minpiv;
+#pragma unroll
+    for (int i = 0; i < K; ++i) { ri[i] = rowid[i]; ri[K + i] = (int)idx[i]; }
+    ri[2 * K] = irregular ? 1 : 0;
+}
+
+// replay of pairs [w0, w0 + cnt) on a tile of targets: grid = (tiles, splits); counts leave as one atomic per target
+template <int D>
+__global__ __launch_bounds__(256) void sxw_apply_kernel(const double *__restrict__ P, i64 n, i64 T, const i64 *__restrict__ targets, i64 m,
+                                                       double tol, i64 samples, u64 seed, i64 w0, i64 cnt,
+                                                       const double *__restrict__ recd, const int *__restrict__ reci,
+                                                       u64 *__restrict__ out) {
+    using C = SxwCfg<D>;
+    constexpr int K = C::K, NL = C::NL, NU = C::NU, DW = C::DW, IW = C::IW, TPT = C::TPT;
+    const int tid = threadIdx.x;
+    const i64 TT = T > 0 ? T : 1;
+    const i64 q0 = (i64)blockIdx.x * (256 * TPT);
+    i64 tg[TPT];
+    bool live[TPT];
+    u64 acc[TPT];
+#pragma unroll
+    for (int p = 0; p < TPT; ++p) {
+        const i64 q = q0 + tid + (i64)p * 256;
+        live[p] = q < m;
+        tg[p] = live[p] ? (targets ? targets[q] : q) : 0;
+        acc[p] = 0;
+    }
+    // this workgroup's slice of the batch: contiguous (the timepoint changes rarely)
+    const i64 per = (cnt + gridDim.y - 1) / gridDim.y;
+    const i64 vbeg = (i64)blockIdx.y * per, vend = vbeg + per < cnt ? vbeg + per : cnt;
+    i64 tcur = -1;
+    double xx[TPT][K], sx[TPT];
+    // A record travels as ONE coalesced load per wave (lane L holds doubles L and 64 + L, and int L), prefetched a pair ahead;
+    // its values reach the arithmetic through v_readlane with compile-time lane numbers: wave-uniform operands in SGPRs without
+    // the scalar cache's latency per value (a scalar load per value, waited for one by one, was ten times slower) and without LDS.
+    static_assert(DW <= 128 && IW <= 64, "a record fits two doubles and one int per lane");
+    const int lane = tid & 63;
+    double c0 = 0.0, c1 = 0.0, n0 = 0.0, n1 = 0.0;
+    int ci = 0, ni = 0;
+    auto fetch = [&](i64 v, double &d0, double &d1, int &di) {
+        const double *rd = recd + (size_t)v * DW;
+        d0 = lane < DW ? rd[lane] : 0.0;
+        d1 = 64 + lane < DW ? rd[64 + lane] : 0.0;
+        di = lane < IW ? reci[(size_t)v * IW + lane] : 0;
+    };
+    if (vbeg < vend) fetch(vbeg, n0, n1, ni);
+#pragma unroll 1
+    for (i64 v = vbeg; v < vend; ++v) {
+        c0 = n0; c1 = n1; ci = ni;
+        if (v + 1 < vend) fetch(v + 1, n0, n1, ni);
+        auto RD = [&](int k) -> double {                                // k: a compile-time constant wherever this is called
+            const unsigned long long bits = (unsigned long long)__double_as_longlong(k < 64 ? c0 : c1);
+            const u32 lo = (u32)__builtin_amdgcn_readlane((int)(u32)bits, k & 63);
+            const u32 hi = (u32)__builtin_amdgcn_readlane((int)(u32)(bits >> 32), k & 63);
+            return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+        };
+        auto RI = [&](int k) -> int { return __builtin_amdgcn_readlane(ci, k); };
+        const i64 t = (w0 + v) / samples;
+        if (t != tcur) {                                                // block-uniform
+            tcur = t;
+#pragma unroll
+            for (int p = 0; p < TPT; ++p) {
+                const double *xp = P + (tg[p] * TT + t) * D;
+                double sc = 1.0;
+                bool isn = false;
+#pragma unroll
+                for (int e = 0; e < D; ++e) {
+                    const double x = xp[e];
+                    xx[p][e] = x;
+                    isn |= x != x;
+                    sc = fabs(x) > sc ? fabs(x) : sc;
+                }
+                xx[p][D] = 1.0;
+                sx[p] = isn ? __builtin_nan("") : sc;
+            }
+        }
+        const double scaleS = RD(2 * NL + NU), minpiv = RD(2 * NL + NU + 1);
+        const int status = RI(2 * K);
+        int perm[K], mem[K];
+#pragma unroll
+        for (int i = 0; i < K; ++i) { perm[i] = RI(i); mem[i] = RI(K + i); }
+        bool special[TPT], in[TPT], skip[TPT];
+        double b[TPT][K], l[TPT][K];
+#pragma unroll
+        for (int p = 0; p < TPT; ++p) {
+            bool member = false;
+#pragma unroll
+            for (int i = 0; i < K; ++i) member |= (i64)mem[i] == tg[p];
+            const double sc = sx[p] > scaleS ? sx[p] : scaleS;          // NaN x: sc = scaleS, and the per-target code says no
+            special[p] = status != 0 || !(sx[p] == sx[p]) || !(minpiv > 1e-10 * sc) || isinf(sc);
+            skip[p] = member;                                           // this target takes a spare subset instead (sxw_spare_kernel)
+            in[p] = true;
+#pragma unroll
+            for (int i = 0; i < K; ++i) b[p][i] = xx[p][perm[i]];
+        }
+        if (status == 0) {                                              // block-uniform
+            int w = 0;
+#pragma unroll
+            for (int i = 1; i < K; ++i)
+#pragma unroll
+                for (int k = 0; k < i; ++k) {
+                    const double f = RD(w++);
+                    if (f != 0.0) {                                     // block-uniform
+#pragma unroll
+                        for (int p = 0; p < TPT; ++p) b[p][i] -= f * b[p][k];
+                    }
+                }
+            w = 0;
+#pragma unroll
+            for (int i = 1; i < K; ++i)
+#pragma unroll
+                for (int k = 0; k < i; ++k) {
+                    const double f = RD(NL + w++);
+#pragma unroll
+                    for (int p = 0; p < TPT; ++p) b[p][i] -= f * b[p][k];
+                }
+#pragma unroll
+            for (int c = K - 1; c >= 0; --c) {
+                const int base = 2 * NL + c * K - c * (c - 1) / 2;      // u[c][c]
+                double sacc[TPT];
+#pragma unroll
+                for (int p = 0; p < TPT; ++p) sacc[p] = b[p][c];
+#pragma unroll
+                for (int k = c + 1; k < K; ++k) {
+                    const double u = RD(base + (k - c));
+#pragma unroll
+                    for (int p = 0; p < TPT; ++p) sacc[p] -= u * l[p][k];
+                }
+                const double dg = RD(base);
+#pragma unroll
+                for (int p = 0; p < TPT; ++p) {
+                    l[p][c] = sacc[p] / dg;
+                    in[p] = in[p] && (l[p][c] >= -tol);
+                }
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < TPT; ++p) {
+            if (!live[p] || skip[p]) continue;
+            int inside = in[p] ? 1 : 0;
+            if (special[p]) {
+                double xv[D];
+#pragma unroll
+                for (int e = 0; e < D; ++e) xv[e] = xx[p][e];
+                inside = sxw_special<D>(P, TT, t, mem, xv, tol);
+            }
+            acc[p] += (u64)inside;
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < TPT; ++p)
+        if (live[p] && acc[p]) atomicAdd(&out[q0 + tid + (i64)p * 256], acc[p]);
+}
+
+// cmem[row] = shared subsets s < samples that contain the row: what a target of that row skips in the replay
+__global__ __launch_bounds__(256) void sxw_members_kernel(i64 n, i64 samples, u64 seed, int k, int *__restrict__ cmem) {
+    const i64 sidx = (i64)blockIdx.x * 256 + threadIdx.x;
+    if (sidx >= samples) return;
+    i64 idx[SMAX];
+    sample_rows(seed, SX_SHARED_KEY, (u64)sidx, k, n, idx);
+    for (int i = 0; i < k; ++i) atomicAdd(&cmem[idx[i]], 1);
+}
+
+// the spare subsets of the targets that skipped some: a thread per (target, timepoint) walks the shared subsets from index
+// `samples` on, takes those that do not contain its target until it has made up what it skipped, and tests each with the
+// per-target code (hull_full_rank, point_in_hull for a degenerate simplex).  K / n of the tests go this way.
+template <int D>
+__global__ __launch_bounds__(256) void sxw_spare_kernel(const double *__restrict__ P, i64 n, i64 T, const i64 *__restrict__ targets, i64 m,
+                                                       double tol, i64 samples, u64 seed, const int *__restrict__ cmem,
+                                                       u64 *__restrict__ out) {
+    constexpr int K = D + 1;
+    const i64 TT = T > 0 ? T : 1;
+    const i64 id = (i64)blockIdx.x * 256 + threadIdx.x;
+    if (id >= m * TT) return;
+    const i64 q = id / TT, t = id % TT;
+    const i64 tg = targets ? targets[q] : q;
+    const int need = cmem[tg];
+    if (need == 0) return;
+    u64 snext = (u64)samples, acc = 0;
+    const double *xx = P + (tg * TT + t) * D;
+    for (int got = 0; got < need; ++got) {
+        i64 idx[K];
+        sample_next_valid(seed, tg, &snext, K, n, idx);
+        double R[K][K + 1];
+        double scale = 1.0;
+        bool anynan = false;
+#pragma unroll
+        for (int c = 0; c < K; ++c) {
+            const double *pp = P + (idx[c] * TT + t) * D;
+#pragma unroll
+            for (int e = 0; e < D; ++e) {
+                const double v = pp[e];
+                anynan |= v != v;
+                R[e][c] = v;
+                scale = fabs(v) > scale ? fabs(v) : scale;
+            }
+            R[D][c] = 1.0;
+        }
+#pragma unroll
+        for (int e = 0; e < D; ++e) {
+            const double v = xx[e];
+            anynan |= v != v;
+            R[e][K] = v;
+            scale = fabs(v) > scale ? fabs(v) : scale;
+        }
+        R[D][K] = 1.0;
+        int res = anynan ? 0 : hull_full_rank<D>(R, scale, tol);
+        if (res == 2) {                                                 // degenerate simplex: generic code, from the data
+            double pts[SMAX * 8], x[8];
+            for (int c = 0; c < K; ++c) {
+                const double *pp = P + (idx[c] * TT + t) * D;
+                for (int e = 0; e < D; ++e) pts[c * D + e] = pp[e];
+            }
+            for (int e = 0; e < D; ++e) x[e] = xx[e];
+            res = point_in_hull(pts, K, D, x, tol) ? 1 : 0;
+        }
+        acc += (u64)res;
+    }
+    if (acc) atomicAdd(&out[q], acc);
+}
+
+template <int D>
+static size_t sxw_pair_bytes() { return SxwCfg<D>::REC + (size_t)(D + 1) * D * 8; }
+size_t simplex_sampled_workspace_bytes(i64 n, i64 T, int d, i64 samples) {
+    if (d < 1 || d > 8 || samples <= 0) return 0;
+    const i64 TT = T > 0 ? T : 1;
+    size_t per = 0;
+    switch (d) {
+#define SX_PB(D_) case D_: per = sxw_pair_bytes<D_>(); break;
+        SX_PB(1) SX_PB(2) SX_PB(3) SX_PB(4) SX_PB(5) SX_PB(6) SX_PB(7) SX_PB(8)
+#undef SX_PB
+    }
+    i64 pairs = samples * TT;
+    if (pairs > ((i64)1 << 20)) pairs = (i64)1 << 20;                   // batches of up to 2^20 pairs: at most ~1.7 GB at d = 8
+    return (size_t)pairs * per + align_up((size_t)n * 4, 256) + 1024;
+}
+
+template <int D>
+static int launch_simplex_ws(const double *P, i64 n, i64 T, const i64 *targets, i64 m, double tol, i64 samples, u64 seed, u64 *out,
+                             void *ws, size_t ws_bytes, hipStream_t s) {
+    using C = SxwCfg<D>;
+    const i64 TT = T > 0 ? T : 1;
+    const i64 pairs = samples * TT;
+    const size_t per = sxw_pair_bytes<D>();
+    const size_t cm_bytes = align_up((size_t)n * 4, 256);
+    if (ws_bytes < 768 + cm_bytes + 256 * per) return fail(SD_ERR_WORKSPACE, "sampled simplex workspace too small");
+    i64 batch = (i64)((ws_bytes - 768 - cm_bytes) / per);
+    if (batch > pairs) batch = pairs;
+    char *w = (char *)(((size_t)ws + 255) / 256 * 256);
+    int *cmem = (int *)w;
+    double *recd = (double *)(w + cm_bytes);
+    double *m1g = recd + (size_t)batch * C::DW;
+    int *reci = (int *)(m1g + (size_t)batch * (C::K * (C::K - 1)));
+    SD_HIP(hipMemsetAsync(cmem, 0, (size_t)n * 4, s));
+    hipLaunchKernelGGL(sxw_members_kernel, dim3((unsigned)((samples + 255) / 256)), dim3(256), 0, s, n, samples, seed, C::K, cmem);
+    const i64 tiles = (m + 256 * C::TPT - 1) / (256 * C::TPT);
+    for (i64 w0 = 0; w0 < pairs; w0 += batch) {
+        const i64 cnt = pairs - w0 < batch ? pairs - w0 : batch;
+        hipLaunchKernelGGL((sxw_factor_kernel<D>), dim3((unsigned)((cnt + 63) / 64)), dim3(64), 0, s, P, n, T, samples, seed, w0, cnt, recd, reci, m1g);
+        i64 splits = (4096 + tiles - 1) / tiles;                        // about 4 096 workgroups in all
+        if (splits > cnt) splits = cnt;
+        if (splits > 65535) splits = 65535;
+        hipLaunchKernelGGL((sxw_apply_kernel<D>), dim3((unsigned)tiles, (unsigned)splits), dim3(256), 0, s, P, n, T, targets, m, tol, samples,
+                           seed, w0, cnt, (const double *)recd, (const int *)reci, out);
+    }
+    hipLaunchKernelGGL((sxw_spare_kernel<D>), dim3((unsigned)((m * TT + 255) / 256)), dim3(256), 0, s, P, n, T, targets, m, tol, samples, seed,
+                       (const int *)cmem, out);
+    SD_HIP(hipGetLastError());
+    return SD_OK;
+}
+
 static int launch_simplex_common(const double *P, i64 n, i64 T, int d, const i64 *targets, i64 m, int relax,
                                  double tol, i64 samples, u64 seed, u64 *out, hipStream_t s,
-                                 SxSel sel = SxSel{nullptr, 0, nullptr, 0}) {
+                                 SxSel sel = SxSel{nullptr, 0, nullptr, 0}, void *ws = nullptr, size_t ws_bytes = 0) {
     SD_HIP(hipMemsetAsync(out, 0, sizeof(u64) * m, s));
     u64 total;
     // subsets per target: of the n - 1 others / of all n rows (external targets) / of the largest block's others
@@ -461,6 +913,18 @@ static int launch_simplex_common(const double *P, i64 n, i64 T, int d, const i64
     if (samples >= 0) total = (u64)samples;
     else if (!binom_u64_checked((u64)pool, d + 1, &total)) return fail(SD_ERR_OVERFLOW, "subset count overflow");
     if (total == 0) return SD_OK;
+    // sampled, targets of the set, counts that add over the timepoints (point clouds, relax=True): the shared factorisation
+    if (samples > 0 && !sel.members && !sel.Q && (T == 0 || relax) && d >= 1 && d <= 8 && n >= d + 3 && xswitch("SD_SIMPLEX_GENERIC") != 1 &&
+        xswitch("SD_SIMPLEX_PERTARGET") != 1) {
+        // with a workspace that holds at least a few hundred records: factor into HBM, replay from there (else the per-target kernels)
+        if (ws && ws_bytes >= simplex_sampled_workspace_bytes(n, T, d, 256 < samples ? 256 : samples)) {
+            switch (d) {
+#define SX_WS(D_) case D_: return launch_simplex_ws<D_>(P, n, T, targets, m, tol, samples, seed, out, ws, ws_bytes, s);
+                SX_WS(1) SX_WS(2) SX_WS(3) SX_WS(4) SX_WS(5) SX_WS(6) SX_WS(7) SX_WS(8)
+#undef SX_WS
+            }
+        }
+    }
     // aim for ~2^18 threads over all targets, at least 1 subset per thread
     u64 want_threads = ((u64)1 << 18) / (u64)(m > 0 ? m : 1);
     if (want_threads < SX_THREADS) want_threads = SX_THREADS;
@@ -492,8 +956,8 @@ static int launch_simplex_common(const double *P, i64 n, i64 T, int d, const i64
 }
 
 int launch_pointcloud_simplex(const double *P, i64 n, int d, const i64 *targets, i64 m, double tol,
-                              i64 samples, u64 seed, u64 *out, hipStream_t s) {
-    return launch_simplex_common(P, n, 0, d, targets, m, 1, tol, samples, seed, out, s);
+                              i64 samples, u64 seed, u64 *out, hipStream_t s, void *ws, size_t ws_bytes) {
+    return launch_simplex_common(P, n, 0, d, targets, m, 1, tol, samples, seed, out, s, SxSel{nullptr, 0, nullptr, 0}, ws, ws_bytes);
 }
 
 // external targets Q (m x d): out[q] = #{(d+1)-subsets of ALL n rows of P whose simplex contains Q[q]}
@@ -509,8 +973,8 @@ int launch_pointcloud_simplex_subsets(const double *P, i64 n, int d, const int *
 }
 
 int launch_multi_simplex(const double *P, i64 n, i64 T, int d, const i64 *targets, i64 m, int relax,
-                         double tol, i64 samples, u64 seed, u64 *out, hipStream_t s) {
-    return launch_simplex_common(P, n, T, d, targets, m, relax, tol, samples, seed, out, s);
+                         double tol, i64 samples, u64 seed, u64 *out, hipStream_t s, void *ws, size_t ws_bytes) {
+    return launch_simplex_common(P, n, T, d, targets, m, relax, tol, samples, seed, out, s, SxSel{nullptr, 0, nullptr, 0}, ws, ws_bytes);
 }
 
 }  // namespace sd

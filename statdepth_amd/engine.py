@@ -417,8 +417,10 @@ def pointcloud_simplex_counts(P, targets=None, tol=1e-7, samples=None, seed=0, d
             check(lib.sd_pointcloud_simplex_counts(Pd.data_ptr(), n, d, tp, m, tol, out.data_ptr(), _stream_ptr(dev)))
     else:
         with t.cuda.device(dev):
+            wsb = int(lib.sd_simplex_sampled_workspace_bytes(n, 0, d, int(samples)))
+            ws = _workspace(dev, wsb)
             check(lib.sd_pointcloud_simplex_sampled(Pd.data_ptr(), n, d, tp, m, tol, int(samples), int(seed),
-                                                out.data_ptr(), _stream_ptr(dev)))
+                                                out.data_ptr(), ws.data_ptr(), wsb, _stream_ptr(dev)))
     return out.cpu().numpy()
 
 
@@ -438,8 +440,10 @@ def multi_simplex_counts(P, targets=None, relax=True, tol=1e-7, samples=None, se
                                           out.data_ptr(), _stream_ptr(dev)))
     else:
         with t.cuda.device(dev):
+            wsb = int(lib.sd_simplex_sampled_workspace_bytes(n, T, d, int(samples)))
+            ws = _workspace(dev, wsb)
             check(lib.sd_multi_simplex_sampled(Pd.data_ptr(), n, T, d, tp, m, int(bool(relax)), tol, int(samples),
-                                           int(seed), out.data_ptr(), _stream_ptr(dev)))
+                                           int(seed), out.data_ptr(), ws.data_ptr(), wsb, _stream_ptr(dev)))
     return out.cpu().numpy()
 
 

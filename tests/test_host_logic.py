@@ -273,6 +273,16 @@ def test_committed_profiles_are_of_the_shipped_kernels():
     assert source and 0.5 * 160.08e6 < traffic < 1.5 * 160.08e6
     kus, ksrc = bench.profiled_kernel_us("rank_bucket32_kernel", 10000, 1000, 2)
     assert ksrc == newest and 20.0 < kus < 80.0
+    # ... and the strict leg's issue roofline from SQ counters collected on the shipped strict kernels (a
+    # constant copied from an earlier round's file is not a measurement of this build)
+    iss = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("issue_strict.json"))
+    assert iss
+    t_iss = last_commit_time([os.path.join("profiles", iss[-1])])
+    t_strict = last_commit_time(["statdepth_amd/csrc/bd_strict.hip"])
+    if t_iss is not None:
+        assert t_iss >= t_strict, f"profiles/{iss[-1]} predates the last change of bd_strict.hip: run tools/issue_strict.py"
+    roof = bench.strict_roofline()
+    assert roof and roof["counter_file"] == os.path.join("profiles", iss[-1])
 
 
 def test_bench_self_launch_plan():
