@@ -6,7 +6,7 @@ import csv, glob, json, os, subprocess, sys
 tag = sys.argv[1] if len(sys.argv) > 1 else "rXX"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 env = dict(os.environ, TMPDIR="/tmp")
-UNITS = {"simplex8": (500 * 256 * 50, "simplex_kernel_fast<8>"), "simplex3": (100000 * 256, "simplex_kernel_fast<3>"),
+UNITS = {"simplex8": (500 * 256 * 50, "sxw_apply_kernel<8>"), "simplex3": (100000 * 256, "sxw_apply_kernel<3>"),
          "l1": (1e10, "l1_depth_kernel<3>"), "strict": (2000 * 1999 * 1998 / 2, "strict_pairs2_kernel")}
 out = {"note": "per launch of the named kernel; SQ_* in wave-instructions / quad-cycles as rocprofv3 reports them (gfx950: SQ_WAVE_CYCLES, "
                "SQ_BUSY_CYCLES, SQ_ACTIVE_INST_VALU count quad-cycles summed over SIMDs).  valu_per_unit = SQ_INSTS_VALU * 64 lanes / units "
