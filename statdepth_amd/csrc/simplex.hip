@@ -877,7 +877,7 @@ static int launch_simplex_ws(const double *P, i64 n, i64 T, const i64 *targets, 
     const i64 pairs = samples * TT;
     const size_t per = sxw_pair_bytes<D>();
     const size_t cm_bytes = align_up((size_t)n * 4, 256);
-    if (ws_bytes < 768 + cm_bytes + 256 * per) return fail(SD_ERR_WORKSPACE, "sampled simplex workspace too small");
+    if (ws_bytes < 768 + cm_bytes + (size_t)(pairs < 256 ? pairs : 256) * per) return fail(SD_ERR_WORKSPACE, "sampled simplex workspace too small");
     i64 batch = (i64)((ws_bytes - 768 - cm_bytes) / per);
     if (batch > pairs) batch = pairs;
     char *w = (char *)(((size_t)ws + 255) / 256 * 256);
