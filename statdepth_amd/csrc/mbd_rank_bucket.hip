@@ -1218,7 +1218,9 @@ static size_t two_level_used_bytes(i64 n, i64 rows) {
            (size_t)rb_cus() * nst * 4 + 256;
 }
 bool rank_bucket_two_level_supported(i64 n, i64 rows) {
-    return rank_bucket32_supported(n, rows, rb_cus()) && two_level_used_bytes(n, rows) + (size_t)n * 8 <= (size_t)2 * rb_cus() * n * 8;
+    // the all-totals block sits behind the largest batch's region (rank_bucket_two_level_all_totals): the same expression here
+    return rank_bucket32_supported(n, rows, rb_cus()) &&
+           align_up(two_level_used_bytes(n, 4096), 256) + (size_t)n * 8 <= mbd_rank_bucket_partial_bytes(n, 2);
 }
 u64 *rank_bucket_two_level_all_totals(u64 *partial, i64 n) {        // sized for the largest batch (4 096 rows)
     return reinterpret_cast<u64 *>(reinterpret_cast<char *>(partial) + align_up(two_level_used_bytes(n, 4096), 256));
