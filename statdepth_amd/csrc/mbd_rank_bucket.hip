@@ -47,16 +47,9 @@ constexpr int RB_MEDIUM_MAXN = 40960;          // rank_medium_image_kernel: 2 or
 #ifndef RB_REDIRECT
 #define RB_REDIRECT 1                          // window reads a bucket does not need go to one shared NaN pair
 #endif
-#ifndef RB_ROBUST
-#define RB_ROBUST 1                            // outlier-robust initial range from the waves' extremes
-#endif
-// The bracket, widened by RB_ROBUST_MARGIN brackets on either side, replaces the range when the range is more than
-// RB_ROBUST_RATIO brackets wide.  The margin is generous on purpose: the bracket is the bulk's +-2.5 sigma only when the
-// waves hold random subsets; curves ordered by level make them stratified and the bracket as narrow as the 9 % .. 93 %
-// quantiles, and then a tight margin would clamp a tail of hundreds of keys into each end bucket (a set-aside row).
-// With 1.5 the bulk still gets a quarter of the buckets or more, and a misfire on stratified heavy-tailed data is mild.
-#define RB_ROBUST_RATIO 8.0
-#define RB_ROBUST_MARGIN 1.5
+// Rows whose range is much wider than their bulk (heavy tails, outlying curves): the three-piece map of rank_bucket.h.  Rounds
+// 1 - 3 clamped the tails into the two end buckets of a range clipped to the waves' innermost extremes: three outlying curves
+// were fine, heavy tails at every timepoint set every row aside for the sort (n = 14 000 Cauchy rows: 3.4 x the Gaussian time).
 #ifndef RB_TIES
 #define RB_TIES 1                              // tie-heavy rows: closed form when every bucket holds one value
 #endif
@@ -139,7 +132,9 @@ struct RBCfg {
     static __host__ __device__ constexpr int dummy_pos(int n) { return (n + RB_PAD + 1) & ~1; }
     static __host__ __device__ constexpr size_t keys_slots(int n) { return (size_t)dummy_pos(n) + 2 * U2 + 2; }
     static constexpr int DEFW = 64;                              // bitmap of set-aside rows: 2048 rows per workgroup and launch
-    static constexpr size_t HDR = (size_t)4 * NW * 8 + (size_t)NW * 4 + (size_t)DEFW * 4 + 64;   // + min/max partials, wave totals
+    // min/max partials, wave totals, bitmap, 64 spare bytes, the waves' brackets ([3][NW] float2: rb3_wave_bracket)
+    static constexpr size_t HDR = (size_t)4 * NW * 8 + (size_t)NW * 4 + (size_t)DEFW * 4 + 64 + (size_t)6 * NW * 4;
+    static constexpr int BRK_WORD = NW + DEFW + 16;                // of the brackets, in u32 words behind the min/max partials
     static __host__ __device__ constexpr size_t lds_bytes(int n) {
         const size_t a = keys_slots(n) * 8 + (size_t)(NB / 2 + 4) * 4;
         const size_t n_act = (size_t)((n + 1023) / 1024) * 1024;
@@ -177,6 +172,7 @@ __global__ __launch_bounds__(NT, (NT == 512 ? 4 : RB_WAVES_PER_EU(E))) void rank
     double *red = Sm;                                                 // [2][NW][2] min/max partials
     u32 *wtot = reinterpret_cast<u32 *>(red + 4 * NW);                // [NW]
     u32 *defer = wtot + NW;                                           // [DEFW] bitmap of the rows set aside
+    float2 *brk = reinterpret_cast<float2 *>(wtot + C::BRK_WORD);     // [3][NW] the waves' brackets: two parities + the second try
     // histogram before the keys: every LDS offset except the keys' end is a compile-time constant
     u32 *H = reinterpret_cast<u32 *>(Sm + C::HDR / 8);                // NB packed u16 counters, then bases
     double *S = reinterpret_cast<double *>(H + NB / 2 + 4);           // keys in bucket order + sentinels + dummy
@@ -316,6 +312,7 @@ __global__ __launch_bounds__(NT, (NT == 512 ? 4 : RB_WAVES_PER_EU(E))) void rank
 #pragma unroll
         for (int j = 0; j < NACC; ++j) acc[e][j] = 0;
 
+    bool heavy = false;                                               // block-uniform: the last row went under the three-piece map
     // (0) range of a row = min / max of its keys (NaN never wins: pandas skipna, _containment.py:68-69), per wave into
     // LDS.  It is computed for the NEXT row at the end of every iteration, where its VALU work fills the waits of
     // the LDS-bound member passes, and once here for the first row.
@@ -325,6 +322,10 @@ __global__ __launch_bounds__(NT, (NT == 512 ? 4 : RB_WAVES_PER_EU(E))) void rank
         for (int e = 0; e < E; ++e) {
             mn = rb_mm<false>(mn, k[e]);
             mx = rb_mm<true>(mx, k[e]);
+        }
+        if (heavy) {                                                  // block-uniform: the bracket of a row that follows a clipped one
+            const float2 wb = rb3_wave_bracket<E, NT>(mn, mx);        // (from the threads' own extremes, before they merge)
+            if ((t & 63) == 63) brk[parity * NW + (t >> 6)] = wb;
         }
         mn = rb_wave_allreduce<false>(mn);
         mx = rb_wave_allreduce<true>(mx);
@@ -355,6 +356,7 @@ __global__ __launch_bounds__(NT, (NT == 512 ? 4 : RB_WAVES_PER_EU(E))) void rank
         const int lane = t & 63;
         const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
         double *redp = red + par * 2 * NW;
+        const float2 *brkp = brk + par * NW;
         par ^= 1;
         mark(0);
         __syncthreads();                                              // barrier 1 (histogram is zero, S is free)
@@ -364,22 +366,6 @@ __global__ __launch_bounds__(NT, (NT == 512 ? 4 : RB_WAVES_PER_EU(E))) void rank
             const double2 p = reinterpret_cast<const double2 *>(redp)[lane & (NW - 1)];
             lo = rb_readlane_f64(rb_row_allreduce<false>(p.x), 0);
             hi = rb_readlane_f64(rb_row_allreduce<true>(p.y), 0);
-            if constexpr (E >= 2 && RB_ROBUST) {
-                // Outlying curves (what depth analysis looks for) stretch the range and squeeze everyone else into
-                // a few buckets.  The 16 waves hold 16 random subsets of the row: the innermost of their minima and
-                // of their maxima bracket the bulk whatever a few waves contain.  When the full range is more than
-                // RB_ROBUST_RATIO times that bracket, the widened bracket is the range (see RB_ROBUST_MARGIN): the tails
-                // clamp into the end buckets -- the map is monotone for ANY lo and scale.  Heuristic values: float.
-                const float l2 = rb_row_allreduce_f32<true>((float)p.x), h2 = rb_row_allreduce_f32<false>((float)p.y);
-                const double lo2 = (double)__int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(l2)));
-                const double hi2 = (double)__int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(h2)));
-                const double sp = hi2 - lo2;
-                if (sp > 0.0 && sp < INF && (hi - lo) > RB_ROBUST_RATIO * sp) {  // block-uniform
-                    const double nlo = lo2 - RB_ROBUST_MARGIN * sp, nhi = hi2 + RB_ROBUST_MARGIN * sp;
-                    lo = nlo > lo ? nlo : lo;
-                    hi = nhi < hi ? nhi : hi;
-                }
-            }
         }
         // range overflow -> 0 -> one crowded bucket; all values equal -> 0 -> one bucket of one value (closed form below)
         const double scale = (hi > lo) ? (double)NB / (hi - lo) : 0.0;
@@ -392,9 +378,44 @@ __global__ __launch_bounds__(NT, (NT == 512 ? 4 : RB_WAVES_PER_EU(E))) void rank
         u32 nn = 0;                                                   // NaN others of this row (block-uniform)
         // block-uniform: a bucket above CAP keys / a bucket of 2^TRYB keys or more (ties?  see the member phase)
         bool crowded = false, trypure = false;
+        // A row whose range is much wider than its bulk (heavy tails, outlying curves) goes under the three-piece map of
+        // rank_bucket.h.  Such a row shows in the histogram of the linear map (a bucket of 2^TRYB keys or more, below) and is
+        // histogrammed again; rows of one matrix resemble each other, so after the first one (`heavy`) the bracket is taken
+        // with the row's range, BEFORE the histogram, until a row needs no clipping again.  Rows that spread well pay nothing.
+        auto bracket_map = [&]() -> Rb3 {
+            double mn = INF, mx = -INF;
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                mn = rb_mm<false>(mn, k[e]);
+                mx = rb_mm<true>(mx, k[e]);
+            }
+            const float2 wb = rb3_wave_bracket<E, NT>(mn, mx);
+            if (lane == 63) brk[2 * NW + wave] = wb;
+            __syncthreads();
+            return rb3_make<NB>(lo, hi, brk[2 * NW + (lane & (NW - 1))], n);
+        };
+        auto histogram_clip = [&](const Rb3 &m3) {
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const double x = k[e];
+                u32 b = rb3_bucket<NB>(m3, x);
+                b = (x == x) ? b : (u32)(NB + 2);
+                const u32 sh = (b & 1u) * 16u;
+                const u32 old = atomicAdd(&H[b >> 1], 1u << sh);
+                bs[e] = b | (((old >> sh) & 0xFFFFu) << 16);
+            }
+        };
         if (go) {
+            Rb3 m3;
+            m3.clip = false;
+            if (heavy) {                                              // block-uniform: the bracket came with the range
+                m3 = rb3_make<NB>(lo, hi, brkp[lane & (NW - 1)], n);
+                heavy = m3.clip;
+            }
             // ---- (1) bucket + slot, branch-free.  min(fl(fl(x - lo) * scale), NB-1), negative -> 0, is non-decreasing
             //      in x for ANY lo and scale >= 0; NaNs count into a dummy word behind the histogram ----
+            if (m3.clip) histogram_clip(m3);
+            else
 #pragma unroll
             for (int e = 0; e < E; ++e) {
                 const double x = k[e];
@@ -419,26 +440,49 @@ __global__ __launch_bounds__(NT, (NT == 512 ? 4 : RB_WAVES_PER_EU(E))) void rank
                 // ---- (2) exclusive prefix sum over the counters (conflict-free 16-byte accesses: lane <-> quad);
                 //      a crowded bucket defers the row ----
                 uint4 hq[QW];
-                u32 runq[QW], inclq[QW], offq[QW], ov = 0, wsum = 0;
+                u32 runq[QW], inclq[QW], offq[QW];
+                auto prefix_a = [&]() {
+                    u32 ov = 0, wsum = 0;
 #pragma unroll
-                for (int i = 0; i < QW; ++i) {
-                    hq[i] = Hq[i * 64 + lane];
-                    const u32 s4 = hq[i].x + hq[i].y + hq[i].z + hq[i].w;   // both halves at once: no half exceeds 16384
-                    ov |= hq[i].x | hq[i].y | hq[i].z | hq[i].w;            // bit k of a half set <=> some counter has it
-                    runq[i] = (s4 & 0xFFFFu) + (s4 >> 16);
-                    inclq[i] = rb_wave_incl_scan(runq[i]);
-                    offq[i] = wsum;
-                    wsum += rb_readlane(inclq[i], 63);
-                }
-                // some counter > CAP (= 2^7 - 1) / some counter >= 2^TRYB: any of the bits from there up is set
-                constexpr u32 HIM = (0xFFFFu & ~(u32)CAP) * 0x10001u, TRM = (0xFFFFu & ~((1u << TRYB) - 1u)) * 0x10001u;
-                const bool wover = __ballot((ov & HIM) != 0) != 0, wtry = __ballot((ov & TRM) != 0) != 0;
-                if (lane == 63) wtot[wave] = wsum | (wover ? 0x80000000u : 0u) | (wtry ? 0x40000000u : 0u);
+                    for (int i = 0; i < QW; ++i) {
+                        hq[i] = Hq[i * 64 + lane];
+                        const u32 s4 = hq[i].x + hq[i].y + hq[i].z + hq[i].w;   // both halves at once: no half exceeds 16384
+                        ov |= hq[i].x | hq[i].y | hq[i].z | hq[i].w;            // bit k of a half set <=> some counter has it
+                        runq[i] = (s4 & 0xFFFFu) + (s4 >> 16);
+                        inclq[i] = rb_wave_incl_scan(runq[i]);
+                        offq[i] = wsum;
+                        wsum += rb_readlane(inclq[i], 63);
+                    }
+                    // some counter > CAP (= 2^7 - 1) / some counter >= 2^TRYB: any of the bits from there up is set
+                    constexpr u32 HIM = (0xFFFFu & ~(u32)CAP) * 0x10001u, TRM = (0xFFFFu & ~((1u << TRYB) - 1u)) * 0x10001u;
+                    const bool wover = __ballot((ov & HIM) != 0) != 0, wtry = __ballot((ov & TRM) != 0) != 0;
+                    if (lane == 63) wtot[wave] = wsum | (wover ? 0x80000000u : 0u) | (wtry ? 0x40000000u : 0u);
+                };
+                prefix_a();
                 mark(3);
                 __syncthreads();                                      // barrier 3
-                const u32 wt = wtot[lane & (NW - 1)];
+                u32 wt = wtot[lane & (NW - 1)];
                 crowded = __ballot((wt >> 31) != 0) != 0;
                 trypure = RB_TIES && __ballot((wt & 0x40000000u) != 0) != 0;
+                if (__ballot((wt & 0x40000000u) != 0) != 0 && !m3.clip) {   // block-uniform, rare
+                    // A bucket of 2^TRYB keys or more under the linear map: tie-heavy data -- or a range much wider than the
+                    // row's bulk.  The bracket tells them apart; the second kind is histogrammed again under core + tails.
+                    m3 = bracket_map();
+                    if (m3.clip) {                                    // block-uniform
+                        heavy = true;
+#pragma unroll
+                        for (int i = 0; i < QW; ++i) Hq[i * 64 + lane] = make_uint4(0, 0, 0, 0);
+                        if (t < 4) H[NB / 2 + t] = 0;
+                        __syncthreads();
+                        histogram_clip(m3);
+                        __syncthreads();
+                        prefix_a();
+                        __syncthreads();
+                        wt = wtot[lane & (NW - 1)];
+                        crowded = __ballot((wt >> 31) != 0) != 0;
+                        trypure = RB_TIES && __ballot((wt & 0x40000000u) != 0) != 0;
+                    }
+                }
                 const u32 wscan = rb_row_incl_scan(wt & 0x3FFFFFFFu);
                 const u32 woff = wave ? rb_readlane(wscan, wave - 1) : 0u;
 #pragma unroll
@@ -789,6 +833,7 @@ __global__ __launch_bounds__(NT) void rank_external_kernel(const double *__restr
     const int n = (int)n64, m = (int)m64;
     double *red = Sm;                                                 // [2][NW][2] min/max partials
     u32 *wtot = reinterpret_cast<u32 *>(red + 4 * NW);                // [NW]
+    float2 *brk = reinterpret_cast<float2 *>(wtot + C::BRK_WORD);     // [NW] the waves' brackets
     u32 *H = reinterpret_cast<u32 *>(Sm + C::HDR / 8);                // NB packed u16 counters, then bases
     double *S = reinterpret_cast<double *>(H + NB / 2 + 4);           // keys in bucket order
     const unsigned short *H16 = reinterpret_cast<const unsigned short *>(H);
@@ -815,6 +860,7 @@ __global__ __launch_bounds__(NT) void rank_external_kernel(const double *__restr
 #pragma unroll
         for (int j = 0; j < JMAX - 1; ++j) acc[q][j] = 0;
     int par = 0;
+    bool heavy = false;                                               // block-uniform: the last row went under the three-piece map
     if ((i64)blockIdx.x < rows) load_row(blockIdx.x);
     for (i64 r = blockIdx.x; r < rows; r += gridDim.x) {
         const i64 rnext = r + gridDim.x;
@@ -833,6 +879,7 @@ __global__ __launch_bounds__(NT) void rank_external_kernel(const double *__restr
             mn = rb_mm<false>(mn, k[e]);
             mx = rb_mm<true>(mx, k[e]);
         }
+        const double tmn = mn, tmx = mx;                              // this thread's own extremes (the bracket's groups)
         mn = rb_wave_allreduce<false>(mn);
         mx = rb_wave_allreduce<true>(mx);
         double *redp = red + par * 2 * NW;
@@ -840,61 +887,88 @@ __global__ __launch_bounds__(NT) void rank_external_kernel(const double *__restr
         par ^= 1;
         __syncthreads();                                              // barrier 1
         double lo, hi;
+        Rb3 m3;
+        m3.clip = false;
         {
             const double2 p = reinterpret_cast<const double2 *>(redp)[lane & (NW - 1)];
             lo = rb_readlane_f64(rb_row_allreduce<false>(p.x), 0);
             hi = rb_readlane_f64(rb_row_allreduce<true>(p.y), 0);
-            if constexpr (E >= 2 && RB_ROBUST) {                      // outlier-robust range, as in rank_bucket_kernel
-                const float l2 = rb_row_allreduce_f32<true>((float)p.x), h2 = rb_row_allreduce_f32<false>((float)p.y);
-                const double lo2 = (double)__int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(l2)));
-                const double hi2 = (double)__int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(h2)));
-                const double sp = hi2 - lo2;
-                if (sp > 0.0 && sp < INF && (hi - lo) > RB_ROBUST_RATIO * sp) {
-                    const double nlo = lo2 - RB_ROBUST_MARGIN * sp, nhi = hi2 + RB_ROBUST_MARGIN * sp;
-                    lo = nlo > lo ? nlo : lo;
-                    hi = nhi < hi ? nhi : hi;
-                }
-            }
         }
         double scale = (double)NB / (hi - lo);
         // equal values, an infinity in the range, a range too small or too large: everything into one bucket
         if (!((hi > lo) && (scale < INF) && (lo > -INF) && (hi < INF))) scale = 0.0;
         auto bucket_of = [&](double x) {
+            if (m3.clip) return rb3_bucket<NB>(m3, x);                // block-uniform
             double u = (x - lo) * scale;
             u = u > 0.0 ? u : 0.0;                                    // below the range, and NaN (0 * inf) -> 0
             u = u < (double)(NB - 1) ? u : (double)(NB - 1);
             return (u32)u;
         };
-        // ---- (1) histogram ----
-        u32 bs[E];
-#pragma unroll
-        for (int e = 0; e < E; ++e) {
-            const double x = k[e];
-            u32 b = bucket_of(x);
-            b = (x == x) ? b : (u32)(NB + 2);
-            const u32 sh = (b & 1u) * 16u;
-            const u32 old = atomicAdd(&H[b >> 1], 1u << sh);
-            bs[e] = b | (((old >> sh) & 0xFFFFu) << 16);
+        // ---- (1) histogram (rows that resemble a clipped one take their bracket first: see rank_bucket_kernel) ----
+        auto bracket_map = [&]() -> Rb3 {
+            const float2 wb = rb3_wave_bracket<E, NT>(tmn, tmx);
+            if (lane == 63) brk[wave] = wb;
+            __syncthreads();
+            return rb3_make<NB>(lo, hi, brk[lane & (NW - 1)], n);
+        };
+        if (heavy) {                                                  // block-uniform
+            m3 = bracket_map();
+            heavy = m3.clip;
         }
+        u32 bs[E];
+        auto histogram = [&]() {
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const double x = k[e];
+                u32 b = bucket_of(x);
+                b = (x == x) ? b : (u32)(NB + 2);
+                const u32 sh = (b & 1u) * 16u;
+                const u32 old = atomicAdd(&H[b >> 1], 1u << sh);
+                bs[e] = b | (((old >> sh) & 0xFFFFu) << 16);
+            }
+        };
+        histogram();
         __syncthreads();                                              // barrier 2
         // ---- (2) exclusive prefix sum ----
         {
             uint4 *Hq = reinterpret_cast<uint4 *>(H) + wave * (64 * QW);
             uint4 hq[QW];
-            u32 runq[QW], inclq[QW], offq[QW], wsum = 0;
+            u32 runq[QW], inclq[QW], offq[QW];
+            auto prefix_a = [&]() {
+                u32 wsum = 0, ov = 0;
 #pragma unroll
-            for (int i = 0; i < QW; ++i) {
-                hq[i] = Hq[i * 64 + lane];
-                const u32 lo16 = (hq[i].x & 0xFFFFu) + (hq[i].y & 0xFFFFu) + (hq[i].z & 0xFFFFu) + (hq[i].w & 0xFFFFu);
-                const u32 hi16 = (hq[i].x >> 16) + (hq[i].y >> 16) + (hq[i].z >> 16) + (hq[i].w >> 16);
-                runq[i] = lo16 + hi16;                                // counters reach n here: no packed addition
-                inclq[i] = rb_wave_incl_scan(runq[i]);
-                offq[i] = wsum;
-                wsum += rb_readlane(inclq[i], 63);
-            }
-            if (lane == 63) wtot[wave] = wsum;
+                for (int i = 0; i < QW; ++i) {
+                    hq[i] = Hq[i * 64 + lane];
+                    const u32 lo16 = (hq[i].x & 0xFFFFu) + (hq[i].y & 0xFFFFu) + (hq[i].z & 0xFFFFu) + (hq[i].w & 0xFFFFu);
+                    const u32 hi16 = (hq[i].x >> 16) + (hq[i].y >> 16) + (hq[i].z >> 16) + (hq[i].w >> 16);
+                    ov |= hq[i].x | hq[i].y | hq[i].z | hq[i].w;      // bit k of a half set <=> some counter has it
+                    runq[i] = lo16 + hi16;                            // counters reach n here: no packed addition
+                    inclq[i] = rb_wave_incl_scan(runq[i]);
+                    offq[i] = wsum;
+                    wsum += rb_readlane(inclq[i], 63);
+                }
+                const bool wtry = __ballot((ov & 0xFFE0FFE0u) != 0) != 0;   // some bucket of 32 keys or more
+                if (lane == 63) wtot[wave] = wsum | (wtry ? 0x40000000u : 0u);
+            };
+            prefix_a();
             __syncthreads();                                          // barrier 3
-            const u32 wscan = rb_row_incl_scan(wtot[lane & 15]);
+            u32 wt = wtot[lane & 15];
+            if (__ballot((wt & 0x40000000u) != 0) != 0 && !m3.clip) { // block-uniform, rare: ties -- or a range much wider than
+                m3 = bracket_map();                                   // the bulk (see rank_bucket_kernel): again under core + tails
+                if (m3.clip) {
+                    heavy = true;
+#pragma unroll
+                    for (int i = 0; i < QW; ++i) Hq[i * 64 + lane] = make_uint4(0, 0, 0, 0);
+                    if (t < 4) H[NB / 2 + t] = 0;
+                    __syncthreads();
+                    histogram();
+                    __syncthreads();
+                    prefix_a();
+                    __syncthreads();
+                    wt = wtot[lane & 15];
+                }
+            }
+            const u32 wscan = rb_row_incl_scan(wt & 0x3FFFFFFFu);
             const u32 woff = wave ? rb_readlane(wscan, wave - 1) : 0u;
 #pragma unroll
             for (int i = 0; i < QW; ++i) {
@@ -1322,6 +1396,7 @@ __global__ __launch_bounds__(NT) void rank_medium_image_kernel(const double *__r
     constexpr int BS = E * NT;                                        // block j: curves [j BS, min((j + 1) BS, n))
     double *red = Sm;                                                 // [2][NW][2] min/max partials
     u32 *wtot = reinterpret_cast<u32 *>(red + 4 * NW);                // [NW]
+    float2 *brk = reinterpret_cast<float2 *>(wtot + C::BRK_WORD);     // [NW] the waves' brackets
     u32 *H = reinterpret_cast<u32 *>(Sm + C::HDR / 8);                // NB packed u16 counters, then bases
     double *S = reinterpret_cast<double *>(H + NB / 2 + 4);           // keys in bucket order
     const unsigned short *H16 = reinterpret_cast<const unsigned short *>(H);
@@ -1337,6 +1412,7 @@ __global__ __launch_bounds__(NT) void rank_medium_image_kernel(const double *__r
         if (t < 4) H[NB / 2 + t] = 0;
     }
     int par = 0;
+    bool heavy = false;                                               // block-uniform: the last block went under the three-piece map
     for (i64 r = blockIdx.x; r < rows; r += gridDim.x) {
         t = t0;
         asm volatile("" : "+v"(t));                                   // per-row opaque thread id (see rank_bucket_kernel)
@@ -1359,6 +1435,7 @@ __global__ __launch_bounds__(NT) void rank_medium_image_kernel(const double *__r
                 mn = rb_mm<false>(mn, xf);
                 mx = rb_mm<true>(mx, xf);
             }
+            const double tmn = mn, tmx = mx;                          // this thread's own extremes (the bracket's groups)
             mn = rb_wave_allreduce<false>(mn);
             mx = rb_wave_allreduce<true>(mx);
             double *redp = red + par * 2 * NW;
@@ -1366,27 +1443,19 @@ __global__ __launch_bounds__(NT) void rank_medium_image_kernel(const double *__r
             par ^= 1;
             __syncthreads();                                          // barrier 1
             double lo, hi;
+            Rb3 m3;
+            m3.clip = false;
             {
                 const double2 p = reinterpret_cast<const double2 *>(redp)[lane & (NW - 1)];
                 lo = rb_readlane_f64(rb_row_allreduce<false>(p.x), 0);
                 hi = rb_readlane_f64(rb_row_allreduce<true>(p.y), 0);
-                if constexpr (RB_ROBUST) {                            // outlier-robust range, as in rank_bucket_kernel
-                    const float l2 = rb_row_allreduce_f32<true>((float)p.x), h2 = rb_row_allreduce_f32<false>((float)p.y);
-                    const double lo2 = (double)__int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(l2)));
-                    const double hi2 = (double)__int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(h2)));
-                    const double sp = hi2 - lo2;
-                    if (sp > 0.0 && sp < INF && (hi - lo) > RB_ROBUST_RATIO * sp) {
-                        const double nlo = lo2 - RB_ROBUST_MARGIN * sp, nhi = hi2 + RB_ROBUST_MARGIN * sp;
-                        lo = nlo > lo ? nlo : lo;
-                        hi = nhi < hi ? nhi : hi;
-                    }
-                }
             }
             const bool flat = hi == lo;                               // every finite key of the block holds one value
             double scale = (double)NB / (hi - lo);
             // equal values, an infinity in the range, a range too small or too large: everything into one bucket
             if (!((hi > lo) && (scale < INF) && (lo > -INF) && (hi < INF))) scale = 0.0;
             auto bucket_of = [&](double x) {
+                if (m3.clip) return rb3_bucket<NB>(m3, x);            // block-uniform
                 double u = (x - lo) * scale;
                 u = u > 0.0 ? u : 0.0;                                // below the range, and NaN (0 * inf) -> 0
                 u = u < (double)(NB - 1) ? u : (double)(NB - 1);
@@ -1394,34 +1463,73 @@ __global__ __launch_bounds__(NT) void rank_medium_image_kernel(const double *__r
             };
             // ---- (1) histogram ----
             u32 bs[E];
-#pragma unroll
-            for (int e = 0; e < E; ++e) {
-                const double x = kk[e];
-                u32 b = bucket_of(x);
-                b = (x == x) ? b : (u32)(NB + 2);
-                const u32 sh = (b & 1u) * 16u;
-                const u32 old = atomicAdd(&H[b >> 1], 1u << sh);
-                bs[e] = b | (((old >> sh) & 0xFFFFu) << 16);
+            bool trypure = false;                                     // block-uniform
+            auto bracket_map = [&]() -> Rb3 {
+                const float2 wb = rb3_wave_bracket<E, NT>(tmn, tmx);
+                if (lane == 63) brk[wave] = wb;
+                __syncthreads();
+                return rb3_make<NB>(lo, hi, brk[lane & (NW - 1)], bsz);
+            };
+            if (heavy && !flat) {                                     // block-uniform: the last block went under core + tails
+                m3 = bracket_map();
+                heavy = m3.clip;
             }
+            auto histogram = [&]() {
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    const double x = kk[e];
+                    u32 b = bucket_of(x);
+                    b = (x == x) ? b : (u32)(NB + 2);
+                    const u32 sh = (b & 1u) * 16u;
+                    const u32 old = atomicAdd(&H[b >> 1], 1u << sh);
+                    bs[e] = b | (((old >> sh) & 0xFFFFu) << 16);
+                }
+            };
+            histogram();
             __syncthreads();                                          // barrier 2
             // ---- (2) exclusive prefix sum ----
             {
                 uint4 *Hq = reinterpret_cast<uint4 *>(H) + wave * (64 * QW);
                 uint4 hq[QW];
-                u32 runq[QW], inclq[QW], offq[QW], wsum = 0;
+                u32 runq[QW], inclq[QW], offq[QW];
+                auto prefix_a = [&]() {
+                    u32 wsum = 0, ov = 0;
 #pragma unroll
-                for (int i = 0; i < QW; ++i) {
-                    hq[i] = Hq[i * 64 + lane];
-                    const u32 lo16 = (hq[i].x & 0xFFFFu) + (hq[i].y & 0xFFFFu) + (hq[i].z & 0xFFFFu) + (hq[i].w & 0xFFFFu);
-                    const u32 hi16 = (hq[i].x >> 16) + (hq[i].y >> 16) + (hq[i].z >> 16) + (hq[i].w >> 16);
-                    runq[i] = lo16 + hi16;
-                    inclq[i] = rb_wave_incl_scan(runq[i]);
-                    offq[i] = wsum;
-                    wsum += rb_readlane(inclq[i], 63);
-                }
-                if (lane == 63) wtot[wave] = wsum;
+                    for (int i = 0; i < QW; ++i) {
+                        hq[i] = Hq[i * 64 + lane];
+                        const u32 lo16 = (hq[i].x & 0xFFFFu) + (hq[i].y & 0xFFFFu) + (hq[i].z & 0xFFFFu) + (hq[i].w & 0xFFFFu);
+                        const u32 hi16 = (hq[i].x >> 16) + (hq[i].y >> 16) + (hq[i].z >> 16) + (hq[i].w >> 16);
+                        ov |= hq[i].x | hq[i].y | hq[i].z | hq[i].w;  // bit k of a half set <=> some counter has it
+                        runq[i] = lo16 + hi16;
+                        inclq[i] = rb_wave_incl_scan(runq[i]);
+                        offq[i] = wsum;
+                        wsum += rb_readlane(inclq[i], 63);
+                    }
+                    // a bucket of 16 keys or more is tie-heavy data more often than a dense cluster (see rank_bucket_kernel)
+                    const bool wtry = __ballot((ov & 0xFFF0FFF0u) != 0) != 0;
+                    if (lane == 63) wtot[wave] = wsum | (wtry ? 0x40000000u : 0u);
+                };
+                prefix_a();
                 __syncthreads();                                      // barrier 3
-                const u32 wscan = rb_row_incl_scan(wtot[lane & 15]);
+                u32 wt = wtot[lane & 15];
+                trypure = __ballot((wt & 0x40000000u) != 0) != 0;
+                if (trypure && !flat && !m3.clip) {                   // block-uniform, rare: ties -- or a range much wider than
+                    m3 = bracket_map();                               // the bulk (see rank_bucket_kernel): again under core + tails
+                    if (m3.clip) {
+                        heavy = true;
+#pragma unroll
+                        for (int i = 0; i < QW; ++i) Hq[i * 64 + lane] = make_uint4(0, 0, 0, 0);
+                        if (t < 4) H[NB / 2 + t] = 0;
+                        __syncthreads();
+                        histogram();
+                        __syncthreads();
+                        prefix_a();
+                        __syncthreads();
+                        wt = wtot[lane & 15];
+                        trypure = __ballot((wt & 0x40000000u) != 0) != 0;
+                    }
+                }
+                const u32 wscan = rb_row_incl_scan(wt & 0x3FFFFFFFu);
                 const u32 woff = wave ? rb_readlane(wscan, wave - 1) : 0u;
 #pragma unroll
                 for (int i = 0; i < QW; ++i) {
@@ -1449,6 +1557,19 @@ __global__ __launch_bounds__(NT) void rank_medium_image_kernel(const double *__r
                 const u32 base = H16[b];
                 S[(b < (u32)NB) ? base + slot : (u32)DUMMY] = kk[e];
             }
+            // Tie-heavy rows (values on a grid, duplicated curves): if every bucket of the block holds ONE value -- every key
+            // equals its bucket's first -- a look-up is a compare with that value, not a walk over hundreds of members
+            bool allpure = false;                                     // block-uniform
+            if (trypure && !flat) {
+                __syncthreads();
+                bool pure = true;
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    const u32 b = bs[e] & 0xFFFFu;
+                    if (b < (u32)NB) pure = pure && (S[H16[b]] == kk[e]);
+                }
+                allpure = __syncthreads_and(pure) != 0;
+            }
             u32 flat_lo = 0, flat_hi = 0;                             // a flat block's -inf / +inf keys
             if (flat) {
                 u32 ml = 0, mh = 0;
@@ -1475,6 +1596,11 @@ __global__ __launch_bounds__(NT) void rank_medium_image_kernel(const double *__r
                     const u32 b = bucket_of(x);
                     const u32 base = H16[b], end = H16[b + 1];
                     u32 less = 0, le = 0;
+                    if (allpure) {                                    // block-uniform: one value per bucket
+                        const double y = S[base < end ? base : 0u];
+                        less = (base < end && y < x) ? end - base : 0u;
+                        le = (base < end && y <= x) ? end - base : 0u;
+                    } else
 #pragma unroll 1
                     for (u32 j = base; j < end; ++j) {
                         const double y = S[j];
