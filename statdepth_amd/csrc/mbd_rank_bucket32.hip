@@ -140,8 +140,19 @@ __global__ __launch_bounds__(R32_NT, 4) void rank_bucket32_kernel(const double *
         const float rmn = rb_row_allreduce_f32<false>(sf == sf ? sf : __builtin_huge_valf());
         const float rmx = rb_row_allreduce_f32<true>(sf == sf ? sf : -__builtin_huge_valf());
         auto rl = [](float v, int l) -> float { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); };
-        const float imn = fmaxf(fmaxf(rl(rmn, 0), rl(rmn, 16)), fmaxf(rl(rmn, 32), rl(rmn, 48)));
-        const float imx = fminf(fminf(rl(rmx, 0), rl(rmx, 16)), fminf(rl(rmx, 32), rl(rmx, 48)));
+        float imn = fmaxf(fmaxf(rl(rmn, 0), rl(rmn, 16)), fmaxf(rl(rmn, 32), rl(rmn, 48)));
+        float imx = fminf(fminf(rl(rmx, 0), rl(rmx, 16)), fminf(rl(rmx, 32), rl(rmx, 48)));
+        // Two sample values of a group of 16 equal (positions scattered over the row): values on a grid.  Such a row is ranked in
+        // closed form when every bucket holds ONE value, which the tail buckets of a clipped map -- octaves wide -- would spoil:
+        // an inverted bracket switches the clipping off for the row (its tails are no heavier for being rounded; if they are
+        // heavy, the row is crowded and handed over as in round 3).
+        {
+            bool eqs = false;                                         // every pair of the group of 16 but those 8 lanes apart
+#define R32_NB(k) eqs = eqs || (__int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(sf), 0x120 + k, 0xF, 0xF, false)) == sf);   // row_ror:k
+            R32_NB(1) R32_NB(2) R32_NB(3) R32_NB(4) R32_NB(5) R32_NB(6) R32_NB(7)
+#undef R32_NB
+            if (__ballot(eqs) != 0) { imn = __builtin_huge_valf(); imx = -__builtin_huge_valf(); }
+        }
         double *rp = red + parity * 4 * NW;
         if ((t & 63) == 63) {
             double *wp = rp + 4 * (t >> 6);
@@ -380,7 +391,9 @@ __global__ __launch_bounds__(R32_NT, 4) void rank_bucket32_kernel(const double *
                 if (vote) misc[2] = tag;
                 if (!same) misc[4] = tag;
                 __syncthreads();
-                if (misc[2] == tag || crowded) {                      // tie-heavy: closed form or hand-over, never the member pass
+                // tie-heavy: closed form, or hand-over when a bucket is beyond the member pass (64 keys); a row with a bucket of 16
+                // equal keys whose other buckets mix values (a clipped map's tail buckets are octaves wide) takes the member pass
+                if ((misc[2] == tag && misc[4] != tag) || crowded) {
                     take = false;
                     bool ok = misc[2] == tag && misc[4] != tag;       // block-uniform
                     if (ok) {
@@ -506,6 +519,7 @@ __global__ __launch_bounds__(R32_NT, 4) void rank_bucket32_kernel(const double *
                         // Keys with equal images have equal B: counted through the (empty) histogram as u16 counters indexed by
                         // B.  The tied ones take their product back and are set aside with B0 = B and the size of their group.
                         expect = have_sum;
+                        const u32 l0 = misc[0];                       // the list before this row (no push since the last barrier)
 #ifdef R32_STAMPS
                         stamp[0] += 1000000;
 #endif
@@ -528,6 +542,60 @@ __global__ __launch_bounds__(R32_NT, 4) void rank_bucket32_kernel(const double *
                             }
                         }
                         __syncthreads();
+#ifndef R32_NO_TIEPROOF                           // (timing experiments: the list alone)
+                        // (E <= 16, n <= 8 192: from E = 18 on this cold code costs the row loop two accumulators in scratch,
+                        // + 5 % on config 2; there a bucket of 16 equal keys is common on such data and the closed form above runs)
+                        if (E <= 16 && misc[0] > (u32)R32_LCAP) {     // block-uniform
+                            // More tied keys than the list takes: values on a grid (rounded measurements) with a few equal keys
+                            // per bucket -- too few for the closed form above to be tried.  Keys with equal images share B, the
+                            // group of B occupies the sorted positions B .. B + c - 1, so its first two slots of S (dead: the
+                            // member pass is over) take the words of its doubles as above: if every group holds ONE value, a tied
+                            // key has B curves strictly below and n - B - c strictly above, and the list is not needed.
+                            const u32 tag = (rowidx + 1u) | 0x40000000u;       // (not the closed form's tag above: it may have failed on this row)
+                            const double *rp = Y + (row0 + r) * n + t;
+#pragma unroll
+                            for (int pass = 0; pass < 2; ++pass) {
+                                bool eq = true;
+#pragma unroll
+                                for (int e0 = 0; e0 < E; e0 += 2) {
+                                    int eo = e0 * NT;
+                                    asm volatile("" : "+v"(eo));
+                                    const double *rq = rp + eo;
+                                    u64 w[2];
+#pragma unroll
+                                    for (int i = 0; i < 2; ++i) {
+                                        const bool isk = e0 + i < E && (e0 + i < E - 2 || t + (e0 + i) * NT < n);
+                                        w[i] = (u64)__double_as_longlong((isk ? rq[i * NT] : 0.0) + 0.0);
+                                    }
+#pragma unroll
+                                    for (int i = 0; i < 2; ++i) {
+                                        if (e0 + i < E && (e0 + i < E - 2 || t + (e0 + i) * NT < n) && H16[kb[e0 + i]] >= 2u) {
+                                            u32 *sp = S + kb[e0 + i];
+                                            if (pass == 0) { sp[0] = (u32)(w[i] >> 32); sp[1] = (u32)w[i]; }
+                                            else eq = eq && sp[0] == (u32)(w[i] >> 32) && sp[1] == (u32)w[i];
+                                        }
+                                    }
+                                    __builtin_amdgcn_sched_barrier(0);
+                                }
+                                if (pass == 1 && !eq) misc[4] = tag;
+                                __syncthreads();
+                            }
+                            if (misc[4] != tag) {                     // block-uniform: proven
+#pragma unroll
+                                for (int e = 0; e < E; ++e) {
+                                    if (e < E - 2 || t + e * NT < n) {
+                                        const u32 B = kb[e], c = H16[B];
+                                        if (c != 1u) {
+                                            const u32 A = (u32)n - B - c;
+                                            acc[e] += (nm1 * (nm1 - 1u) - A * (A - 1u) - B * (B - 1u)) >> 1;
+                                        }
+                                    }
+                                }
+                                if (t == 0) misc[0] = l0;             // this row's entries are dropped
+                            }
+                            __syncthreads();
+                        }
+#endif
 #pragma unroll
                         for (int e = 0; e < E; ++e)
                             if (e < E - 2 || t + e * NT < n) H[kb[e] >> 1] = 0;

@@ -7,8 +7,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import torch
 from statdepth_amd import engine, _native
-if os.environ.get("SD_LIB"):                     # experiments: another build of the library (this tool only)
-    _native.LIB_PATH = os.path.abspath(os.environ["SD_LIB"])
+if os.environ.get("SD_LIB"):                     # experiments: another build of the library (this tool only; the cross-check
+    _native.LIB_PATH = os.path.abspath(os.environ["SD_LIB"])      # build too, which the package itself refuses to load)
+    _native._LIB = _native.open_library(_native.LIB_PATH)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
 T = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 30
