@@ -727,7 +727,7 @@ __global__ __launch_bounds__(NT, (NT == 512 ? 4 : RB_WAVES_PER_EU(E))) void rank
     for (int e = 0; e < E; ++e)
         if ((J > 0) && (e < E - 1 || t + (E - 1) * NT < n)) {
             if constexpr (J == 2) {
-                if constexpr (SEL) P32[t + e * NT] = (u32)(acc[e][0] >> 1);
+                if constexpr (SEL) { if ((i64)blockIdx.x < rows) P32[t + e * NT] = (u32)(acc[e][0] >> 1); }   // (else: never read)
                 else if (p32) P32[t + e * NT] = (u32)(acc[e][0] >> 1);
                 else P[t + e * NT] = acc[e][0] >> 1;
             } else {
@@ -772,6 +772,7 @@ __global__ __launch_bounds__(NT, (NT == 512 ? 4 : RB_WAVES_PER_EU(E))) void rank
         //      for workgroups that are already running (a ticket is taken at the end of the work, and all but K - 1 others
         //      have left by then), so the wait ends whatever share of the CUs this launch gets. ----
         const int G = (int)gridDim.x, K = G < 16 ? G : 16;
+        const int Gs = rows < (i64)G ? (int)rows : G;                 // workgroups that had a flagged row: the others' blocks are not read
         __syncthreads();                                              // this workgroup's block is complete (stores acknowledged) ...
         if (t0 == 0) {
             __threadfence();                                          // ... and written back for the device (ONE fence per workgroup)
@@ -794,7 +795,7 @@ __global__ __launch_bounds__(NT, (NT == 512 ? 4 : RB_WAVES_PER_EU(E))) void rank
             if (qb + qx < q1) {
                 const u32 *pp = fblocks + 4 * (qb + qx);
 #pragma unroll 8
-                for (int g = y; g < G; g += 16) {
+                for (int g = y; g < Gs; g += 16) {
                     const uint4 v = *reinterpret_cast<const uint4 *>(pp + (size_t)g * nst);
                     a0 += v.x; a1 += v.y; a2 += v.z; a3 += v.w;
                 }
