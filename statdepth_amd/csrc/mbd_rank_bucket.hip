@@ -157,7 +157,8 @@ __global__ __launch_bounds__(NT, (NT == 512 ? 4 : RB_WAVES_PER_EU(E))) void rank
                                                          const u32 *__restrict__ gate = nullptr, u32 epoch = 0,
                                                          u64 *__restrict__ out_tot = nullptr, int Gsum = 0,
                                                          const u32 *__restrict__ listbuf = nullptr,
-                                                         u32 *__restrict__ fblocks = nullptr, u32 *__restrict__ done = nullptr) {
+                                                         u32 *__restrict__ fblocks = nullptr, u32 *__restrict__ done = nullptr,
+                                                         int kspin = 1) {
     // J == 0: image mode (J >= 4 on the host side): no fold, the pairs (B | A << 16) of every (row, curve) go to the
     // pair image `partial` (as u32[rows][n]) and the rows' NaN counts to nnan_img; rank_accumulate*_kernel folds them
     using C = RBCfg<NT, E, LNB, U2>;
@@ -768,10 +769,11 @@ __global__ __launch_bounds__(NT, (NT == 512 ? 4 : RB_WAVES_PER_EU(E))) void rank
     if constexpr (SEL) {
         // ---- the flagged rows' totals: G blocks of u32 -> out_tot.  Adding them with atomics from every workgroup costs
         //      G same-address atomics per curve (20 us at G = 256); instead each workgroup publishes its block, takes a
-        //      ticket, and the LAST workgroups to arrive each sum one slice of the curves over all blocks.  They wait only
-        //      for workgroups that are already running (a ticket is taken at the end of the work, and all but K - 1 others
-        //      have left by then), so the wait ends whatever share of the CUs this launch gets. ----
-        const int G = (int)gridDim.x, K = G < 16 ? G : 16;
+        //      ticket, and the LAST K workgroups to arrive each sum one slice of the curves over all blocks.  A waiting
+        //      workgroup holds its CU, so the wait ends only if the workgroups that have not started yet still find one: the
+        //      host passes K = kspin <= (workgroups the launch's CUs hold at once) - 1 (launch_bucket_sel_cfg: occupancy x the
+        //      stream's CU mask; every workgroup resident at once: 16), and K = 1 never waits. ----
+        const int G = (int)gridDim.x, K = G < kspin ? G : (kspin < 1 ? 1 : kspin);
         const int Gs = rows < (i64)G ? (int)rows : G;                 // workgroups that had a flagged row: the others' blocks are not read
         __syncthreads();                                              // this workgroup's block is complete (stores acknowledged) ...
         if (t0 == 0) {
@@ -1191,7 +1193,7 @@ static int launch_bucket_cfg(const double *Y, i64 n, i64 row0, i64 rows, u64 *pa
     if (lds > 163840) return fail(SD_ERR_UNSUPPORTED, "bucket kernel: %zu bytes of LDS for n=%lld", lds, (long long)n);
     SD_HIP(hipFuncSetAttribute((const void *)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kf, dim3(G), dim3(NT), lds, s, Y, n, row0, rows, partial, p32, nnan_img, (const unsigned char *)nullptr,
-                       (const u32 *)nullptr, 0u, (u64 *)nullptr, 0, (const u32 *)nullptr, (u32 *)nullptr, (u32 *)nullptr);
+                       (const u32 *)nullptr, 0u, (u64 *)nullptr, 0, (const u32 *)nullptr, (u32 *)nullptr, (u32 *)nullptr, 1);
     SD_HIP(hipGetLastError());
     return SD_OK;
 }
@@ -1206,8 +1208,30 @@ static int launch_bucket_sel_cfg(const double *Y, i64 n, i64 row0, i64 rows, u64
     const size_t lds = C::lds_bytes((int)n) + 8192;
     if (lds > 163840) return fail(SD_ERR_UNSUPPORTED, "bucket kernel: %zu bytes of LDS for n=%lld", lds, (long long)n);
     SD_HIP(hipFuncSetAttribute((const void *)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    // workgroups that may wait for the others at the end of the kernel: fewer than the launch's CUs hold at once
+    int kspin = 1;
+    {
+        static int occ_cached = 0;                            // per instantiation (benign race: same value)
+        int occ = occ_cached;
+        if (occ <= 0) {
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)kf, 1024, lds) != hipSuccess || occ < 1) occ = 1;
+            occ_cached = occ;
+        }
+        int usable = rb_cus();
+        uint32_t mask[16] = {0};
+        if (hipExtStreamGetCUMask(s, 16, mask) == hipSuccess) {
+            int bits = 0;
+            for (int i = 0; i < 16; ++i) bits += __builtin_popcount(mask[i]);
+            if (bits > 0 && bits < usable) usable = bits;
+        } else {
+            (void)hipGetLastError();
+        }
+        const long cap = (long)occ * usable;
+        kspin = cap >= G ? 16 : (int)(cap - 1 < 16 ? cap - 1 : 16);
+        if (kspin < 1) kspin = 1;
+    }
     hipLaunchKernelGGL(kf, dim3(G), dim3(1024), lds, s, Y, n, row0, rows, partial, 2, (u32 *)nullptr, rowflag, gate, epoch, out, Gsum, listbuf,
-                       fblocks, done);
+                       fblocks, done, kspin);
     SD_HIP(hipGetLastError());
     return SD_OK;
 }
