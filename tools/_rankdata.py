@@ -18,4 +18,8 @@ def rank_data(n, T):
         X[:, np.random.default_rng(9).choice(n, size=int(os.environ["SD_OUTLIER_RANDOM"]), replace=False)] *= 1e6
     if os.environ.get("SD_CAUCHY"):                  # heavy tails at every timepoint
         X = np.random.default_rng(5).standard_cauchy(size=(T, n))
+    if os.environ.get("SD_NANROWS"):                 # a NaN in each of that many rows (rows left to the second launch)
+        g = np.random.default_rng(11)
+        for r in g.choice(T, size=int(os.environ["SD_NANROWS"]), replace=False):
+            X[r, g.integers(0, n)] = np.nan
     return X
