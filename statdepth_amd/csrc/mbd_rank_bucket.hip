@@ -21,6 +21,10 @@
 //      integer data, a row of equal values -- the ranks are closed form (less = 0, le = count) and the row needs no
 //      member pass at all.  A row with an infinity, or with a bucket above CAP keys that mixes values, is set aside
 //      and sorted by the same workgroup behind its row loop (rb_slow_row).
+//      Rows much wider than their bulk (heavy tails, outlying curves): a row whose histogram shows a crowded bucket and
+//      whose range exceeds the central bracket of its threads' own keys many times over is histogrammed again under the
+//      three-piece map of rank_bucket.h (linear core + float-like tails, monotone for any data); the rows behind it take
+//      their bracket with their range.  The external-target and medium kernels below use the same map.
 //   Z  rank_finalize_kernel / rank_finalize4_kernel -- totals of the requested targets = sum of the workgroups'
 //      partials (+ the fold of pair-image rows when the caller supplies one).
 //
