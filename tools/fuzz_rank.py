@@ -15,7 +15,9 @@ for c in range(cases):
     T = int(rng.integers(1, 12))
     if 16384 < n <= 40960 and rng.random() < 0.7:
         T = int(rng.integers(96, 104))                        # the medium route (column blocks) takes over from 96 rows on
-    kind = rng.choice(["normal", "walk", "ints", "round", "cauchy", "const", "lognormal", "tiny", "huge"])
+    if rng.random() < 0.12:
+        T = int(rng.integers(260, 640))                       # more rows than workgroups: the bracket-with-the-range mode of the map
+    kind = rng.choice(["normal", "walk", "ints", "round", "cauchy", "const", "lognormal", "tiny", "huge", "mixed"])
     X = rng.normal(size=(T, n))
     if kind == "walk": X = X.cumsum(axis=0)
     elif kind == "ints": X = rng.integers(-3, 4, size=(T, n)).astype(float)
@@ -25,6 +27,9 @@ for c in range(cases):
     elif kind == "lognormal": X = np.exp(X * 5)
     elif kind == "tiny": X = X * 1e-312
     elif kind == "huge": X = X * 1e307
+    elif kind == "mixed":                                     # heavy-tailed and Gaussian stretches of rows taking turns
+        hv = (np.arange(T) // int(rng.integers(1, 120))) % 2 == 1
+        X[hv] = rng.standard_cauchy(size=(int(hv.sum()), n)) * rng.choice([1.0, 1e-3, 1e5])
     # outlying curves / entries (robust range), values a hair apart (mixed buckets), blocks of equal values inside
     # continuous rows (tie path with and without crowding)
     if rng.random() < 0.35: X[:, rng.choice(n, size=min(n, int(rng.choice([1, 3, 17, max(1, n // 50)]))), replace=False)] *= rng.choice([1e3, 1e6, 1e12])
