@@ -22,6 +22,10 @@
 //   quarter of the row tied on one value, say) is cut into chunks of 16 384 keys in curve order:
 //   chunk_sort_kernel sorts every chunk, chunk_search_kernel streams every sorted chunk of the row through
 //   LDS and sums lower/upper bounds per chunk: O((n/C)^2) chunk searches per row instead of none.
+// The product path launches B and route 2 as ONE kernel per batch, big_fallback_kernel: flagged buckets first, then -- for
+//   the rows whose partition overflowed -- chunk sort, a meeting of the (CU-resident) grid at a counter, chunk search; with
+//   nothing flagged every workgroup reads two gate words and leaves.  The separate kernels stay for the cross-check
+//   switches (chunked route for every row, earlier generations).
 // Work per row, route 1: one streaming pass + n/5 500 LDS sorts; config 3 (10^5 x 256) on one MI355X:
 // see DESIGN.md.
 #include <stdlib.h>
@@ -83,13 +87,10 @@ using BigCfg = R2Cfg<BIG_NT, BIG_E>;
 
 // persistent 1-D grid over (chunk, row); rowflag != nullptr: only rows with a non-zero flag (none: every workgroup reads
 // a few flags and leaves)
-__global__ __launch_bounds__(BIG_NT) void chunk_sort_kernel(const double *__restrict__ Y, i64 n, i64 row0, i64 rows, i64 nch,
-                                                            double *__restrict__ sorted, i64 sstride,
-                                                            u32 *__restrict__ nanrow, const u32 *__restrict__ rowflag,
-                                                            const u32 *__restrict__ gate, u32 epoch) {
+__device__ __forceinline__ void chunk_sort_items(const double *__restrict__ Y, i64 n, i64 row0, i64 rows, i64 nch,
+                                                 double *sorted, i64 sstride, u32 *nanrow,
+                                                 const u32 *__restrict__ rowflag, double *Sm) {
     constexpr int E = BIG_E, WB = BigCfg::WB;
-    extern __shared__ double Sm[];
-    if (gate && *gate != epoch) return;                       // no row of this batch overflowed its value buckets
     for (i64 v = blockIdx.x; v < rows * nch; v += gridDim.x) {
     const i64 c = v % nch, rb = v / nch;
     if (rowflag && !rowflag[rb]) continue;
@@ -127,24 +128,29 @@ __global__ __launch_bounds__(BIG_NT) void chunk_sort_kernel(const double *__rest
     }
 }
 
-// grid = G persistent workgroups; workgroup g owns curve chunk g % nchunks and rows g / nchunks + k * (G / nchunks)
-__global__ __launch_bounds__(BIG_NT) void chunk_search_kernel(const double *__restrict__ Y, i64 n, i64 row0,
-                                                              i64 rows, const double *__restrict__ sorted,
-                                                              i64 sstride, const u32 *__restrict__ nanrow,
-                                                              int nchunks, const u32 *__restrict__ rowflag,
-                                                              const u32 *__restrict__ gate, u32 epoch, AB2 ab) {
-    constexpr int E = BIG_E, WB = BigCfg::WB, N = BIG_C;
+__global__ __launch_bounds__(BIG_NT) void chunk_sort_kernel(const double *__restrict__ Y, i64 n, i64 row0, i64 rows, i64 nch,
+                                                            double *__restrict__ sorted, i64 sstride,
+                                                            u32 *__restrict__ nanrow, const u32 *__restrict__ rowflag,
+                                                            const u32 *__restrict__ gate, u32 epoch) {
     extern __shared__ double Sm[];
     if (gate && *gate != epoch) return;                       // no row of this batch overflowed its value buckets
-    const int t = threadIdx.x;
-    const int qc = (int)(blockIdx.x % nchunks);
-    const int rgroups = gridDim.x / nchunks;
-    const i64 qbase = (i64)qc * BIG_C;
-    const int nq = (int)((n - qbase) < BIG_C ? (n - qbase) : BIG_C);
-    const double INF = __builtin_huge_val();
+    chunk_sort_items(Y, n, row0, rows, nch, sorted, sstride, nanrow, rowflag, Sm);
+}
 
-    for (i64 rb = blockIdx.x / nchunks; rb < rows; rb += rgroups) {
+// persistent 1-D grid over the items (row, query chunk): the chunk's curves are searched in every sorted chunk of the row
+__device__ __forceinline__ void chunk_search_items(const double *__restrict__ Y, i64 n, i64 row0, i64 rows,
+                                                   const double *sorted, i64 sstride, const u32 *nanrow, int nchunks,
+                                                   const u32 *__restrict__ rowflag, const AB2 &ab, double *Sm) {
+    constexpr int E = BIG_E, WB = BigCfg::WB, N = BIG_C;
+    const double INF = __builtin_huge_val();
+    for (i64 v = blockIdx.x; v < rows * nchunks; v += gridDim.x) {
+        const i64 rb = v / nchunks;
         if (rowflag && !rowflag[rb]) continue;
+        int t = threadIdx.x;
+        asm volatile("" : "+v"(t));                           // per-item opaque thread id
+        const int qc = (int)(v % nchunks);
+        const i64 qbase = (i64)qc * BIG_C;
+        const int nq = (int)((n - qbase) < BIG_C ? (n - qbase) : BIG_C);
         const double *xp = Y + (row0 + rb) * n + qbase + t;
         double x[E];
         u32 lo[E], hi[E];
@@ -188,6 +194,16 @@ __global__ __launch_bounds__(BIG_NT) void chunk_search_kernel(const double *__re
             }
         }
     }
+}
+
+__global__ __launch_bounds__(BIG_NT) void chunk_search_kernel(const double *__restrict__ Y, i64 n, i64 row0,
+                                                              i64 rows, const double *__restrict__ sorted,
+                                                              i64 sstride, const u32 *__restrict__ nanrow,
+                                                              int nchunks, const u32 *__restrict__ rowflag,
+                                                              const u32 *__restrict__ gate, u32 epoch, AB2 ab) {
+    extern __shared__ double Sm[];
+    if (gate && *gate != epoch) return;                       // no row of this batch overflowed its value buckets
+    chunk_search_items(Y, n, row0, rows, sorted, sstride, nanrow, nchunks, rowflag, ab, Sm);
 }
 
 // =====================================================================================================
@@ -1116,7 +1132,7 @@ __global__ __launch_bounds__(P3_NT) void bucket_partition3_kernel(const double *
     }
     for (int o = 32; o > 0; o >>= 1) mynan += __shfl_down(mynan, o);
     if (lane == 0 && mynan) atomicAdd(&nnanrow[rb], mynan);
-    if (over) { ovf[rb] = 1u; gate[1] = epoch; }                       // a gate word is "set" when it holds the batch's epoch
+    if (over) { ovf[rb] = 1u; gate[2] = 0u; gate[1] = epoch; }         // a gate word is "set" when it holds the batch's epoch; [2]: the fall-back kernel's meeting counter
 }
 
 // A3: grid = 8 * NBT * ceil(rows / 8) (the XCD-aware mapping of bucket_rank_kernel), 512 threads x 16 keys
@@ -1352,19 +1368,16 @@ __global__ __launch_bounds__(A3_NT) SD_A3_ATTR void bucket_rank32_kernel(const d
 // B: persistent 1-D grid over the (row, bucket) pairs, flagged buckets only (nothing flagged: every workgroup reads a few
 // flags and leaves).  rowtied == nullptr or rowtied[row]: fp64 records (bval, bidx); else 8-byte records whose keys are
 // gathered from the matrix through their curve indices.
-__global__ __launch_bounds__(BK_NT) void bucket_search_kernel(const double *__restrict__ Y, i64 n, i64 row0, i64 rows, int NB,
-                                                              const u32 *__restrict__ bcnt,
-                                                              const u32 *__restrict__ nnanrow,
-                                                              const u32 *__restrict__ bflag,
-                                                              const u32 *__restrict__ rowtied,
-                                                              const double *__restrict__ bval,
-                                                              const u32 *__restrict__ bidx,
-                                                              const u32 *__restrict__ gate, u32 epoch, AB2 ab) {
-    using C = BkCfg;
-    constexpr int E = BK_E, NT = BK_NT, LE = C::LE, WB = C::WB, N = C::N;
-    extern __shared__ double Sm[];
+template <int NT, int E>
+__device__ __forceinline__ void bucket_search_items(const double *__restrict__ Y, i64 n, i64 row0, i64 rows, int NB,
+                                                    const u32 *__restrict__ bcnt, const u32 *__restrict__ nnanrow,
+                                                    const u32 *__restrict__ bflag, const u32 *__restrict__ rowtied,
+                                                    const double *__restrict__ bval, const u32 *__restrict__ bidx,
+                                                    const AB2 &ab, double *Sm) {
+    using C = R2Cfg<NT, E>;
+    constexpr int LE = C::LE, WB = C::WB, N = C::N;
+    static_assert(NT * E >= BK_C, "a value bucket fits the sort");
     __shared__ u32 s_basecnt;
-    if (gate && *gate != epoch) return;                               // no bucket of this batch was flagged
     const u64 *rec = reinterpret_cast<const u64 *>(bval);
     for (i64 v = blockIdx.x; v < rows * NB; v += gridDim.x) {
         if (!bflag[v]) continue;                                      // block-uniform
@@ -1418,6 +1431,51 @@ __global__ __launch_bounds__(BK_NT) void bucket_search_kernel(const double *__re
             ab_store(ab, (size_t)(rb * n + id), base + (u32)lo, (x == INF) ? 0u : nreal - (base + (u32)hi), nreal);
         }
     }
+}
+
+__global__ __launch_bounds__(BK_NT) void bucket_search_kernel(const double *__restrict__ Y, i64 n, i64 row0, i64 rows, int NB,
+                                                              const u32 *__restrict__ bcnt,
+                                                              const u32 *__restrict__ nnanrow,
+                                                              const u32 *__restrict__ bflag,
+                                                              const u32 *__restrict__ rowtied,
+                                                              const double *__restrict__ bval,
+                                                              const u32 *__restrict__ bidx,
+                                                              const u32 *__restrict__ gate, u32 epoch, AB2 ab) {
+    extern __shared__ double Sm[];
+    if (gate && *gate != epoch) return;                               // no bucket of this batch was flagged
+    bucket_search_items<BK_NT, BK_E>(Y, n, row0, rows, NB, bcnt, nnanrow, bflag, rowtied, bval, bidx, ab, Sm);
+}
+
+// The three fall-backs of a batch in ONE launch (product path): flagged value buckets (gate[0]), then the chunked route for
+// the rows whose partition overflowed (gate[1]): every workgroup sorts its share of the rows' chunks, the grid meets at a
+// counter (gate[2], zeroed by whoever set gate[1]), every workgroup searches its share of (row, chunk) items.  The grid is
+// no larger than what the launch's CUs hold at once (big_fallback_grid), so every workgroup the others wait for is running.
+// Nothing flagged: every workgroup reads the two gate words and leaves.
+__global__ __launch_bounds__(BIG_NT) void big_fallback_kernel(const double *__restrict__ Y, i64 n, i64 row0, i64 rows, int NBT,
+                                                              const u32 *__restrict__ bcnt,
+                                                              const u32 *__restrict__ nnanrow,
+                                                              const u32 *__restrict__ bflag,
+                                                              const u32 *__restrict__ rowtied,
+                                                              const double *__restrict__ bval,
+                                                              const u32 *__restrict__ bidx, double *sorted, i64 sstride,
+                                                              u32 *nanf, int nch, const u32 *__restrict__ ovf,
+                                                              u32 *gate, u32 epoch, AB2 ab) {
+    extern __shared__ double Sm[];
+    const bool flagged = gate[0] == epoch, over = gate[1] == epoch;   // block-uniform
+    if (!flagged && !over) return;
+    if (flagged) bucket_search_items<BIG_NT, BIG_E>(Y, n, row0, rows, NBT, bcnt, nnanrow, bflag, rowtied, bval, bidx, ab, Sm);
+    if (!over) return;
+    __syncthreads();
+    chunk_sort_items(Y, n, row0, rows, nch, sorted, sstride, nanf, ovf, Sm);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();                                              // the sorted chunks and the NaN counts, device-wide
+        atomicAdd(&gate[2], 1u);
+        while (__hip_atomic_load(&gate[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x) __builtin_amdgcn_s_sleep(16);
+        __threadfence();
+    }
+    __syncthreads();
+    chunk_search_items(Y, n, row0, rows, sorted, sstride, nanf, nch, ovf, ab, Sm);
 }
 
 // =====================================================================================================
@@ -1772,6 +1830,21 @@ static int big_run(const double *Y, i64 T, i64 n, const i64 *targets, i64 tbegin
         if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
     }
     const unsigned pgrid = (unsigned)cus;                   // small persistent grids of the fallback kernels
+    // The merged fall-back kernel's workgroups wait for each other: its grid is what the launch's CUs hold at once
+    // (one workgroup on each CU the stream may use), never more.
+    unsigned fgrid = 1;
+    {
+        int usable = cus;
+        uint32_t mask[16] = {0};
+        if (hipExtStreamGetCUMask(s, 16, mask) == hipSuccess) {
+            int bits = 0;
+            for (int i = 0; i < 16; ++i) bits += __builtin_popcount(mask[i]);
+            if (bits > 0 && bits < usable) usable = bits;
+        } else {
+            (void)hipGetLastError();
+        }
+        fgrid = (unsigned)(usable < 1 ? 1 : usable);         // one workgroup per CU (a kernel that launches at all fits once)
+    }
     auto k_cs = chunk_sort_kernel;
     auto k_cq = chunk_search_kernel;
     // sample per row: 2 048 values up to 24 value buckets (>= 85 samples per bucket), 4 096 up to 72, 16 384 above.
@@ -1792,6 +1865,7 @@ static int big_run(const double *Y, i64 T, i64 n, const i64 *targets, i64 tbegin
     SD_HIP(hipFuncSetAttribute((const void *)bucket_partition3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_p3));
     SD_HIP(hipFuncSetAttribute((const void *)bucket_rank32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)A3_LDS));
     SD_HIP(hipFuncSetAttribute((const void *)k_bs, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BkCfg::LDS_BYTES));
+    SD_HIP(hipFuncSetAttribute((const void *)big_fallback_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BigCfg::LDS_BYTES));
 #ifdef SD_CROSSCHECK
     auto k_br = bucket_rank_kernel;
     SD_HIP(hipFuncSetAttribute((const void *)k_br, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BR_LDS));
@@ -1813,6 +1887,7 @@ static int big_run(const double *Y, i64 T, i64 n, const i64 *targets, i64 tbegin
         const u32 *fallback_rows = nullptr;                  // chunked route: every row
         const u32 *nn_for_fold = nanf;
         const u32 *gate_o = nullptr;                         // no gate: the chunk kernels look at every row flag
+        bool merged = false;
         if (img_out) ab.B = img_out + (size_t)row0 * n;      // image mode: the B words straight into the caller's image
         u32 epoch = ++epoch_counter;
         if (epoch == 0) epoch = ++epoch_counter;
@@ -1834,12 +1909,15 @@ static int big_run(const double *Y, i64 T, i64 n, const i64 *targets, i64 tbegin
             hipLaunchKernelGGL(bucket_rank32_kernel, dim3((unsigned)(8 * NBT * ((rows + 7) / 8))), dim3(A3_NT), A3_LDS, s, Y, n,
                                row0, rows, NBT, (const u32 *)bcnt, (const u32 *)nnanrow, (const u32 *)ovf,
                                (const u32 *)rowtied, (const u64 *)bval, (const u32 *)bidx, bflag, gate, epoch, ab);
-            hipLaunchKernelGGL(k_bs, dim3(pgrid), dim3(BK_NT), BkCfg::LDS_BYTES, s, Y, n, row0, rows, NBT, (const u32 *)bcnt,
-                               (const u32 *)nnanrow, (const u32 *)bflag, (const u32 *)rowtied, (const double *)bval,
-                               (const u32 *)bidx, (const u32 *)gate, epoch, ab);
-            fallback_rows = ovf;                             // chunked route: only rows whose partition overflowed
+            // the fall-backs (flagged buckets; chunked route for rows whose partition overflowed) behind their gate words
+            hipLaunchKernelGGL(big_fallback_kernel, dim3(fgrid), dim3(BIG_NT), BigCfg::LDS_BYTES, s, Y, n, row0, rows, NBT,
+                               (const u32 *)bcnt, (const u32 *)nnanrow, (const u32 *)bflag, (const u32 *)rowtied,
+                               (const double *)bval, (const u32 *)bidx, sorted, p.sstride, nanf, (int)p.nch,
+                               (const u32 *)ovf, gate, epoch, ab);
+            fallback_rows = ovf;
             nn_for_fold = nnanrow;
             gate_o = gate + 1;
+            merged = true;
         }
 #ifdef SD_CROSSCHECK
         if (buckets && gen2) {
@@ -1872,8 +1950,8 @@ static int big_run(const double *Y, i64 T, i64 n, const i64 *targets, i64 tbegin
             nn_for_fold = nnanrow;
         }
 #endif
-        // chunked route: every row (cross-check switch) or the rows whose partition overflowed (none: both launches are
-        // small persistent grids that read a few flags and leave)
+        // chunked route: every row (cross-check switches)
+        if (!merged) {
         const unsigned csgrid = fallback_rows ? pgrid : (unsigned)(p.nch * rows < 65535 * 16 ? p.nch * rows : 65535 * 16);
         hipLaunchKernelGGL(k_cs, dim3(csgrid), dim3(BIG_NT), BigCfg::LDS_BYTES, s, Y, n, row0, rows, p.nch,
                            sorted, p.sstride, nanf, fallback_rows, gate_o, epoch);
@@ -1882,6 +1960,7 @@ static int big_run(const double *Y, i64 T, i64 n, const i64 *targets, i64 tbegin
         if (rgroups > rows) rgroups = rows;
         hipLaunchKernelGGL(k_cq, dim3((unsigned)(rgroups * p.nch)), dim3(BIG_NT), BigCfg::LDS_BYTES, s, Y, n, row0, rows,
                            (const double *)sorted, p.sstride, (const u32 *)nanf, (int)p.nch, fallback_rows, gate_o, epoch, ab);
+        }
         SD_HIP(hipGetLastError());
         if (img_out) {
             SD_HIP(hipMemcpyAsync(nnan_out + row0, nn_for_fold, (size_t)rows * 4, hipMemcpyDeviceToDevice, s));
