@@ -140,10 +140,11 @@ __global__ __launch_bounds__(BIG_NT) void chunk_sort_kernel(const double *__rest
 // persistent 1-D grid over the items (row, query chunk): the chunk's curves are searched in every sorted chunk of the row
 __device__ __forceinline__ void chunk_search_items(const double *__restrict__ Y, i64 n, i64 row0, i64 rows,
                                                    const double *sorted, i64 sstride, const u32 *nanrow, int nchunks,
-                                                   const u32 *__restrict__ rowflag, const AB2 &ab, double *Sm) {
+                                                   const u32 *__restrict__ rowflag, const AB2 &ab, double *Sm,
+                                                   i64 vfirst, i64 vstride) {
     constexpr int E = BIG_E, WB = BigCfg::WB, N = BIG_C;
     const double INF = __builtin_huge_val();
-    for (i64 v = blockIdx.x; v < rows * nchunks; v += gridDim.x) {
+    for (i64 v = vfirst; v < rows * nchunks; v += vstride) {
         const i64 rb = v / nchunks;
         if (rowflag && !rowflag[rb]) continue;
         int t = threadIdx.x;
@@ -203,7 +204,7 @@ __global__ __launch_bounds__(BIG_NT) void chunk_search_kernel(const double *__re
                                                               const u32 *__restrict__ gate, u32 epoch, AB2 ab) {
     extern __shared__ double Sm[];
     if (gate && *gate != epoch) return;                       // no row of this batch overflowed its value buckets
-    chunk_search_items(Y, n, row0, rows, sorted, sstride, nanrow, nchunks, rowflag, ab, Sm);
+    chunk_search_items(Y, n, row0, rows, sorted, sstride, nanrow, nchunks, rowflag, ab, Sm, blockIdx.x, gridDim.x);
 }
 
 // =====================================================================================================
@@ -826,13 +827,15 @@ __device__ __forceinline__ u32 rb_wave_allreduce_u32(u32 v) {
 }
 
 // S3: grid = rows.  NB = interior buckets; NBT = NB + 2 buckets and NS = NB + 1 splitters per row.
+constexpr int FB_MEET_WORDS_S3 = 2 + 1024;                             // = FB_MEET_WORDS (checked where that is defined)
 template <int SNT, int SE>
 __global__ __launch_bounds__(SNT) void bucket_setup_kernel(const double *__restrict__ Y, i64 n, i64 row0, int NB,
                                                            double *__restrict__ spl, double *__restrict__ mk,
                                                            u32 *__restrict__ tab, double2 *__restrict__ rp,
                                                            u32 *__restrict__ rowtied, u32 *__restrict__ bcnt,
                                                            u32 *__restrict__ bflag, u32 *__restrict__ nnanrow,
-                                                           u32 *__restrict__ ovf, u32 *__restrict__ nanf) {
+                                                           u32 *__restrict__ ovf, u32 *__restrict__ nanf,
+                                                           u32 *__restrict__ meet) {
     using Cfg = R2Cfg<SNT, SE>;
     constexpr int E = SE, LE = Cfg::LE, SS = SNT * SE, NWV = SNT / 64, CPT = TB_C / SNT;
     static_assert(TB_C % SNT == 0, "whole cells per thread");
@@ -865,6 +868,8 @@ __global__ __launch_bounds__(SNT) void bucket_setup_kernel(const double *__restr
         bflag[rb * NBT + b] = 0;
     }
     if (t == 0) { nnanrow[rb] = 0; ovf[rb] = 0; nanf[rb] = 0; }
+    if (rb == 0)                                                       // the batch's meeting words (big_fallback_kernel)
+        for (int c = t; c < FB_MEET_WORDS_S3; c += SNT) meet[c] = 0;
     R2Sorter<SNT, SE>::sort(k, Sm, t, SS, true, INF);
     double *Sw = Sm + r2_base<0, LE>(t);
 #pragma unroll
@@ -1132,7 +1137,7 @@ __global__ __launch_bounds__(P3_NT) void bucket_partition3_kernel(const double *
     }
     for (int o = 32; o > 0; o >>= 1) mynan += __shfl_down(mynan, o);
     if (lane == 0 && mynan) atomicAdd(&nnanrow[rb], mynan);
-    if (over) { ovf[rb] = 1u; gate[2] = 0u; gate[1] = epoch; }         // a gate word is "set" when it holds the batch's epoch; [2]: the fall-back kernel's meeting counter
+    if (over) { ovf[rb] = 1u; gate[1] = epoch; }                       // a gate word is "set" when it holds the batch's epoch
 }
 
 // A3: grid = 8 * NBT * ceil(rows / 8) (the XCD-aware mapping of bucket_rank_kernel), 512 threads x 16 keys
@@ -1448,9 +1453,20 @@ __global__ __launch_bounds__(BK_NT) void bucket_search_kernel(const double *__re
 
 // The three fall-backs of a batch in ONE launch (product path): flagged value buckets (gate[0]), then the chunked route for
 // the rows whose partition overflowed (gate[1]): every workgroup sorts its share of the rows' chunks, the grid meets at a
-// counter (gate[2], zeroed by whoever set gate[1]), every workgroup searches its share of (row, chunk) items.  The grid is
-// no larger than what the launch's CUs hold at once (big_fallback_grid), so every workgroup the others wait for is running.
-// Nothing flagged: every workgroup reads the two gate words and leaves.
+// counter, every workgroup searches its share of (row, chunk) items.  Nothing flagged: every workgroup reads the two gate
+// words and leaves.
+// The meeting (meet[], zeroed by S3 every batch): [0] arrivals, [1] workgroups that gave up waiting, [2 + w] who searches
+// workgroup w's items.  The grid is one workgroup per CU the stream may use, so every workgroup the others wait for is
+// running -- unless something the host cannot see keeps CUs from this launch (a process-wide mask, another process).  So the
+// wait is bounded: a workgroup that has waited spin_limit polls announces it, looks once more, and leaves its items to the
+// LAST workgroup to arrive, which exists whatever happens (nobody waits for a workgroup that has not sorted yet without
+// eventually making room for it) and sweeps the claim words when anybody gave up.  A claim word changes once, by
+// compare-and-swap (0 -> FB_SELF by its owner, FB_LEFT by its owner on leaving, FB_TAKEN by the last arriver): every item is
+// searched exactly once.
+constexpr u32 FB_SELF = 1u, FB_LEFT = 2u, FB_TAKEN = 3u;
+constexpr int FB_MAXGRID = 1024;
+constexpr int FB_MEET_WORDS = 2 + FB_MAXGRID;
+static_assert(FB_MEET_WORDS == FB_MEET_WORDS_S3, "S3 zeroes the meeting words");
 __global__ __launch_bounds__(BIG_NT) void big_fallback_kernel(const double *__restrict__ Y, i64 n, i64 row0, i64 rows, int NBT,
                                                               const u32 *__restrict__ bcnt,
                                                               const u32 *__restrict__ nnanrow,
@@ -1459,8 +1475,10 @@ __global__ __launch_bounds__(BIG_NT) void big_fallback_kernel(const double *__re
                                                               const double *__restrict__ bval,
                                                               const u32 *__restrict__ bidx, double *sorted, i64 sstride,
                                                               u32 *nanf, int nch, const u32 *__restrict__ ovf,
-                                                              u32 *gate, u32 epoch, AB2 ab) {
+                                                              const u32 *__restrict__ gate, u32 epoch, u32 *meet,
+                                                              u32 spin_limit, AB2 ab) {
     extern __shared__ double Sm[];
+    __shared__ u32 s_role;                                            // 0: leave, 1: search my items, 2: ... and sweep
     const bool flagged = gate[0] == epoch, over = gate[1] == epoch;   // block-uniform
     if (!flagged && !over) return;
     if (flagged) bucket_search_items<BIG_NT, BIG_E>(Y, n, row0, rows, NBT, bcnt, nnanrow, bflag, rowtied, bval, bidx, ab, Sm);
@@ -1468,14 +1486,49 @@ __global__ __launch_bounds__(BIG_NT) void big_fallback_kernel(const double *__re
     __syncthreads();
     chunk_sort_items(Y, n, row0, rows, nch, sorted, sstride, nanf, ovf, Sm);
     __syncthreads();
+    const u32 G = gridDim.x, me = blockIdx.x;
+    auto arrived = [&]() { return __hip_atomic_load(&meet[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
     if (threadIdx.x == 0) {
         __threadfence();                                              // the sorted chunks and the NaN counts, device-wide
-        atomicAdd(&gate[2], 1u);
-        while (__hip_atomic_load(&gate[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x) __builtin_amdgcn_s_sleep(16);
+        const u32 ticket = atomicAdd(&meet[0], 1u);
+        const bool last = ticket + 1u == G;
+        bool full = last;
+        for (u32 spins = 0; !full && spins < spin_limit; ++spins) {
+            __builtin_amdgcn_s_sleep(32);
+            full = arrived() >= G;
+        }
+        if (!full) {                                                  // waited long enough: say so, then look once more
+            atomicAdd(&meet[1], 1u);
+            __threadfence();
+            full = arrived() >= G;
+        }
+        u32 role = 0;
+        if (full) role = atomicCAS(&meet[2 + me], 0u, FB_SELF) == 0u ? 1u : 0u;
+        else atomicCAS(&meet[2 + me], 0u, FB_LEFT);
+        if (last) role |= 2u;
         __threadfence();
+        s_role = role;
     }
     __syncthreads();
-    chunk_search_items(Y, n, row0, rows, sorted, sstride, nanf, nch, ovf, ab, Sm);
+    const u32 role = s_role;
+    if (role & 1u) chunk_search_items(Y, n, row0, rows, sorted, sstride, nanf, nch, ovf, ab, Sm, me, G);
+    if (!(role & 2u)) return;
+    // the last arriver: did anybody give up?  (Whoever did said so before its last look at the arrivals, which did not
+    // include this workgroup's.)
+    __syncthreads();
+    if (threadIdx.x == 0) s_role = __hip_atomic_load(&meet[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (s_role == 0u) return;
+    for (u32 w = 0; w < G; ++w) {
+        if (w == me) continue;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const u32 v = atomicCAS(&meet[2 + w], 0u, FB_TAKEN);
+            s_role = (v == 0u || v == FB_LEFT) ? 1u : 0u;
+        }
+        __syncthreads();
+        if (s_role) chunk_search_items(Y, n, row0, rows, sorted, sstride, nanf, nch, ovf, ab, Sm, w, G);
+    }
 }
 
 // =====================================================================================================
@@ -1720,7 +1773,7 @@ struct BigPlan {
     int NB, NBT;                                         // interior value buckets; NBT = NB + 2 with the two end buckets
     size_t off_ab, off_h, off_sorted, off_bval, off_bidx, off_spl, off_mk, off_tab, off_rp, off_zero, zero_bytes, total;
     // zeroed block: bcnt[rpb*NBT] | nnanrow[rpb] | ovf[rpb] | bflag[rpb*NBT] | nanrow_f[rpb] | rowtied[rpb]
-    size_t z_bcnt, z_nnan, z_ovf, z_bflag, z_nanf, z_tied, z_gate;
+    size_t z_bcnt, z_nnan, z_ovf, z_bflag, z_nanf, z_tied, z_gate, z_meet;
 };
 
 static BigPlan big_plan(i64 T, i64 n) {
@@ -1759,6 +1812,7 @@ static BigPlan big_plan(i64 T, i64 n) {
     p.z_nanf = ztake((size_t)r * 4);
     p.z_tied = ztake((size_t)r * 4);
     p.z_gate = ztake(16 * 4);                                // per batch: [0] some bucket flagged, [1] some row overflowed
+    p.z_meet = ztake((size_t)FB_MEET_WORDS * 4);             // the fall-back kernel's meeting
     p.zero_bytes = z;
     p.total = o + z + 256;
     return p;
@@ -1810,6 +1864,7 @@ static int big_run(const double *Y, i64 T, i64 n, const i64 *targets, i64 tbegin
     u32 *bcnt = (u32 *)(zb + p.z_bcnt), *nnanrow = (u32 *)(zb + p.z_nnan), *ovf = (u32 *)(zb + p.z_ovf);
     u32 *bflag = (u32 *)(zb + p.z_bflag), *nanf = (u32 *)(zb + p.z_nanf), *rowtied = (u32 *)(zb + p.z_tied);
     u32 *gate = (u32 *)(zb + p.z_gate);
+    u32 *meet = (u32 *)(zb + p.z_meet);
     // A gate word is "set" when it holds the batch's epoch (a process-wide counter, never 0): nothing has to zero it, and
     // stale workspace contents can at worst make a fallback kernel scan flags that S3 has zeroed -- time, never results.
     static std::atomic<u32> epoch_counter{0};
@@ -1833,6 +1888,10 @@ static int big_run(const double *Y, i64 T, i64 n, const i64 *targets, i64 tbegin
     // The merged fall-back kernel's workgroups wait for each other: its grid is what the launch's CUs hold at once
     // (one workgroup on each CU the stream may use), never more.
     unsigned fgrid = 1;
+    // polls (about a microsecond each) before a waiting workgroup leaves its items to the last arriver; cross-check builds:
+    // SD_BIG_SPIN = 1 makes every workgroup but the last give up at once (the take-over path under test)
+    u32 spin_limit = 1u << 20;
+    if (xswitch("SD_BIG_SPIN") > 0) spin_limit = (u32)xswitch("SD_BIG_SPIN") - 1u;
     {
         int usable = cus;
         uint32_t mask[16] = {0};
@@ -1844,6 +1903,7 @@ static int big_run(const double *Y, i64 T, i64 n, const i64 *targets, i64 tbegin
             (void)hipGetLastError();
         }
         fgrid = (unsigned)(usable < 1 ? 1 : usable);         // one workgroup per CU (a kernel that launches at all fits once)
+        if (fgrid > (unsigned)FB_MAXGRID) fgrid = FB_MAXGRID;
     }
     auto k_cs = chunk_sort_kernel;
     auto k_cq = chunk_search_kernel;
@@ -1896,13 +1956,13 @@ static int big_run(const double *Y, i64 T, i64 n, const i64 *targets, i64 tbegin
             // ---- third generation: S3 -> P3 -> A3 (untied rows) / A' (tied rows) ----
             if (NB <= 24)
                 hipLaunchKernelGGL(k_s3_small, dim3((unsigned)rows), dim3(128), lds_sp_small, s, Y, n, row0, NB, spl, mk, tab,
-                                   rp, rowtied, bcnt, bflag, nnanrow, ovf, nanf);
+                                   rp, rowtied, bcnt, bflag, nnanrow, ovf, nanf, meet);
             else if (NB <= 72)
                 hipLaunchKernelGGL(k_s3, dim3((unsigned)rows), dim3(256), lds_sp, s, Y, n, row0, NB, spl, mk, tab, rp,
-                                   rowtied, bcnt, bflag, nnanrow, ovf, nanf);
+                                   rowtied, bcnt, bflag, nnanrow, ovf, nanf, meet);
             else
                 hipLaunchKernelGGL(k_s3_big, dim3((unsigned)rows), dim3(1024), lds_sp_big, s, Y, n, row0, NB, spl, mk, tab,
-                                   rp, rowtied, bcnt, bflag, nnanrow, ovf, nanf);
+                                   rp, rowtied, bcnt, bflag, nnanrow, ovf, nanf, meet);
             hipLaunchKernelGGL(bucket_partition3_kernel, dim3((unsigned)((n + P3_C - 1) / P3_C), (unsigned)rows), dim3(P3_NT),
                                lds_p3, s, Y, n, row0, NBT, (const double *)spl, (const double *)mk, (const u32 *)tab,
                                (const double2 *)rp, (const u32 *)rowtied, bcnt, nnanrow, ovf, (u64 *)bval, bidx, gate, epoch, ab);
@@ -1913,7 +1973,7 @@ static int big_run(const double *Y, i64 T, i64 n, const i64 *targets, i64 tbegin
             hipLaunchKernelGGL(big_fallback_kernel, dim3(fgrid), dim3(BIG_NT), BigCfg::LDS_BYTES, s, Y, n, row0, rows, NBT,
                                (const u32 *)bcnt, (const u32 *)nnanrow, (const u32 *)bflag, (const u32 *)rowtied,
                                (const double *)bval, (const u32 *)bidx, sorted, p.sstride, nanf, (int)p.nch,
-                               (const u32 *)ovf, gate, epoch, ab);
+                               (const u32 *)ovf, (const u32 *)gate, epoch, meet, spin_limit, ab);
             fallback_rows = ovf;
             nn_for_fold = nnanrow;
             gate_o = gate + 1;

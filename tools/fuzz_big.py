@@ -35,6 +35,9 @@ for c in range(cases):
         c0 = int(rng.integers(0, n - w))
         v = X[:, c0:c0 + 1].copy()
         X[:, c0:c0 + w] = np.where(rng.random((T, w)) < 0.5, v, v * (1 + rng.choice([0.0, 1e-15, 1e-12])))
+    if rng.random() < 0.3:                       # rows with a large share on ONE value: the partition overflows a value bucket
+        for r in rng.choice(T, size=int(rng.integers(1, T + 1)), replace=False):      # (chunked route inside the fall-back launch)
+            X[r, rng.random(n) < rng.choice([0.1, 0.3, 0.7, 0.95])] = rng.normal()
     if rng.random() < 0.4: X[rng.random(X.shape) < rng.choice([0.0005, 0.02, 0.5])] = np.nan
     if rng.random() < 0.3: X[rng.random(X.shape) < 0.001] = np.inf
     if rng.random() < 0.3: X[rng.random(X.shape) < 0.001] = -np.inf
