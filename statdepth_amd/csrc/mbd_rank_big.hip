@@ -1776,6 +1776,9 @@ struct BigPlan {
     size_t z_bcnt, z_nnan, z_ovf, z_bflag, z_nanf, z_tied, z_gate, z_meet;
 };
 
+#ifndef SD_BIG_SCRATCH_BYTES
+#define SD_BIG_SCRATCH_BYTES ((size_t)1 << 32)
+#endif
 static BigPlan big_plan(i64 T, i64 n) {
     BigPlan p;
     p.nch = big_nchunks(n);
@@ -1784,7 +1787,10 @@ static BigPlan big_plan(i64 T, i64 n) {
     p.NBT = p.NB + 2;
     const size_t per_row = (size_t)n * 8 + (size_t)p.sstride * 8 + (size_t)p.NBT * BK_C * 12 + (size_t)p.NBT * 32 +
                            (size_t)TB_C * 4 + 128;
-    i64 r = (i64)(((size_t)3 << 29) / per_row);           // ~1.5 GiB of scratch per batch
+    // Scratch per batch: every batch costs 40 - 45 us by itself (S3's latency in front of the partition, the kernels' tails, the
+    // fold's launch; profiles/r04_experiment_rows_per_batch.txt), and 288 GB of HBM have room: 4 GiB take 10^5 curves x 1 000
+    // timepoints in one batch (1.5 GiB: three).
+    i64 r = (i64)((size_t)SD_BIG_SCRATCH_BYTES / per_row);
     const i64 vb = xswitch("SD_RANK_ROWS_PER_BATCH");          // cross-check builds: several batches on small inputs
     if (vb > 0 && vb < r) r = vb;
     if (r < 1) r = 1;
