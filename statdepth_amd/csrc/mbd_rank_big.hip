@@ -943,8 +943,11 @@ __global__ __launch_bounds__(SNT) void bucket_setup_kernel(const double *__restr
     }
 }
 
-// P3: grid = (ceil(n / 4096), rows), 512 threads x 8 keys
-constexpr int P3_NT = 512, P3_E = 8, P3_C = P3_NT * P3_E;
+// P3: grid = (ceil(n / 3072), rows), 512 threads x 6 keys
+#ifndef SD_P3_E
+#define SD_P3_E 6                      // 8: 4 096 keys per block and three workgroups per CU -- + 2 ... 3 % at every size measured
+#endif
+constexpr int P3_NT = 512, P3_E = SD_P3_E, P3_C = P3_NT * P3_E;
 static inline size_t p3_lds_bytes(int NBT) {
     return (size_t)P3_C * 8 + (size_t)(2 * NBT + 2) * 8 + (size_t)TB_C * 4 + (size_t)(3 * NBT + 4 + P3_NT / 64) * 4 + (size_t)P3_C * 2 + 64;
 }
@@ -958,7 +961,9 @@ __global__ __launch_bounds__(P3_NT) void bucket_partition3_kernel(const double *
                                                                   u32 *__restrict__ ovf, u64 *__restrict__ rec,
                                                                   u32 *__restrict__ bidx, u32 *__restrict__ gate,
                                                                   u32 epoch, AB2 ab) {
-    // One block of 4 096 curves of one row per workgroup, three workgroups per CU.  (Measured and dropped: 4 consecutive
+    // One block of 3 072 curves of one row per workgroup, four workgroups per CU up to ~30 value buckets (40 KB of LDS; with
+    // 4 096 curves: three).  Keys per thread 4 / 5 / 6 / 7 / 8 / 10 at config 3: 0.272 / 0.265 / 0.267 / 0.278 / 0.274 / 0.293 ms
+    // (profiles/r04_p3_keys_per_thread.txt).  (Measured and dropped: 4 consecutive
     // blocks per workgroup with the next block's keys prefetched and the row's table loaded once -- 95 VGPRs, two workgroups
     // per CU, 128 us against 111 us at config 3: the third resident workgroup hides more latency than the prefetch.)
     extern __shared__ double Sm3[];
