@@ -210,8 +210,12 @@ __global__ __launch_bounds__(BIG_NT) void chunk_search_kernel(const double *__re
 // =====================================================================================================
 // route 1: value buckets
 // =====================================================================================================
-constexpr int BK_NT = 512, BK_E = 16;
-constexpr int BK_C = BK_NT * BK_E;             // bucket capacity 8192
+#ifndef SD_BK_CE
+#define SD_BK_CE 16                            // keys per thread of the ranking kernels = bucket capacity / 512
+#endif
+constexpr int BK_NT = 512, BK_E = 16;          // the search kernel's sort: 8 192 slots
+constexpr int BK_C = BK_NT * SD_BK_CE;         // bucket capacity (8 192)
+static_assert(BK_C <= BK_NT * BK_E, "a value bucket fits the search kernel's sort");
 #ifndef SD_BK_FILL
 #define SD_BK_FILL 5500
 #endif
@@ -222,7 +226,7 @@ using BkCfg = R2Cfg<BK_NT, BK_E>;
 static inline int bucket_count(i64 n) {
     // mean fill 5 500 of 8 192; past ~300 buckets even the 16 384-value sample leaves < 50 samples per bucket and the
     // fills scatter too much: aim lower
-    const i64 fill = n > 1600000 ? 3800 : BK_FILL;
+    const i64 fill = n > 1600000 ? (i64)BK_FILL * 3800 / 5500 : BK_FILL;
     i64 nb = (n + fill - 1) / fill;
     if (nb < 2) nb = 2;
     return (int)nb;
@@ -544,7 +548,7 @@ __global__ __launch_bounds__(BK_NT) void bucket_packed_kernel(i64 n, int NB, con
 #ifndef SD_BR_U2
 #define SD_BR_U2 3
 #endif
-constexpr int BR_NT = 512, BR_E = 16, BR_LNB = 12, BR_NBF = 1 << BR_LNB, BR_CAP = 63, BR_TRYB = 4, BR_U2 = SD_BR_U2, BR_PAD = 8;
+constexpr int BR_NT = 512, BR_E = SD_BK_CE, BR_LNB = 12, BR_NBF = 1 << BR_LNB, BR_CAP = 63, BR_TRYB = 4, BR_U2 = SD_BR_U2, BR_PAD = 8;
 static_assert(((BR_CAP + 1) & BR_CAP) == 0, "the crowding test reads the counters' bits");
 constexpr int BR_NW = BR_NT / 64;
 static_assert(BR_NT * BR_E == BK_C, "one thread slot per key of a full value bucket");
@@ -1146,7 +1150,7 @@ __global__ __launch_bounds__(P3_NT) void bucket_partition3_kernel(const double *
 }
 
 // A3: grid = 8 * NBT * ceil(rows / 8) (the XCD-aware mapping of bucket_rank_kernel), 512 threads x 16 keys
-constexpr int A3_NT = 512, A3_E = 16, A3_LNB = 12, A3_NBF = 1 << A3_LNB, A3_CAP = 63, A3_U = 2, A3_PAD = 32;
+constexpr int A3_NT = 512, A3_E = SD_BK_CE, A3_LNB = 12, A3_NBF = 1 << A3_LNB, A3_CAP = 63, A3_U = 2, A3_PAD = 32;
 constexpr int A3_NW = A3_NT / 64;
 static_assert(A3_NT * A3_E == BK_C, "one thread slot per key of a full value bucket");
 static_assert(A3_NBF / 2 / A3_NT == 4, "one 16-byte quad of histogram words per thread");
@@ -1784,6 +1788,10 @@ struct BigPlan {
 #ifndef SD_BIG_SCRATCH_BYTES
 #define SD_BIG_SCRATCH_BYTES ((size_t)1 << 32)
 #endif
+#ifndef SD_S3_SMALL_NB
+#define SD_S3_SMALL_NB 24
+#endif
+constexpr int S3_SMALL_NB = SD_S3_SMALL_NB;             // up to that many value buckets: the 2 048-key sample
 static BigPlan big_plan(i64 T, i64 n) {
     BigPlan p;
     p.nch = big_nchunks(n);
@@ -1965,7 +1973,7 @@ static int big_run(const double *Y, i64 T, i64 n, const i64 *targets, i64 tbegin
         if (!buckets || gen2) SD_HIP(hipMemsetAsync(zb, 0, p.zero_bytes, s));      // (the third generation's S3 zeroes)
         if (buckets && !gen2) {
             // ---- third generation: S3 -> P3 -> A3 (untied rows) / A' (tied rows) ----
-            if (NB <= 24)
+            if (NB <= S3_SMALL_NB)
                 hipLaunchKernelGGL(k_s3_small, dim3((unsigned)rows), dim3(128), lds_sp_small, s, Y, n, row0, NB, spl, mk, tab,
                                    rp, rowtied, bcnt, bflag, nnanrow, ovf, nanf, meet);
             else if (NB <= 72)
