@@ -1792,6 +1792,10 @@ struct BigPlan {
 #define SD_S3_SMALL_NB 24
 #endif
 constexpr int S3_SMALL_NB = SD_S3_SMALL_NB;             // up to that many value buckets: the 2 048-key sample
+#ifndef SD_S3_MID_NB
+#define SD_S3_MID_NB 72
+#endif
+constexpr int S3_MID_NB = SD_S3_MID_NB;                 // ... the 4 096-key sample; beyond: 16 384 keys
 static BigPlan big_plan(i64 T, i64 n) {
     BigPlan p;
     p.nch = big_nchunks(n);
@@ -1976,7 +1980,7 @@ static int big_run(const double *Y, i64 T, i64 n, const i64 *targets, i64 tbegin
             if (NB <= S3_SMALL_NB)
                 hipLaunchKernelGGL(k_s3_small, dim3((unsigned)rows), dim3(128), lds_sp_small, s, Y, n, row0, NB, spl, mk, tab,
                                    rp, rowtied, bcnt, bflag, nnanrow, ovf, nanf, meet);
-            else if (NB <= 72)
+            else if (NB <= S3_MID_NB)
                 hipLaunchKernelGGL(k_s3, dim3((unsigned)rows), dim3(256), lds_sp, s, Y, n, row0, NB, spl, mk, tab, rp,
                                    rowtied, bcnt, bflag, nnanrow, ovf, nanf, meet);
             else
