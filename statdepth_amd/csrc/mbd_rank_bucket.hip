@@ -1222,16 +1222,21 @@ static int launch_bucket_sel_cfg(const double *Y, i64 n, i64 row0, i64 rows, u64
             occ_cached = occ;
         }
         int usable = rb_cus();
+        bool masked = false;
         uint32_t mask[16] = {0};
         if (hipExtStreamGetCUMask(s, 16, mask) == hipSuccess) {
             int bits = 0;
             for (int i = 0; i < 16; ++i) bits += __builtin_popcount(mask[i]);
-            if (bits > 0 && bits < usable) usable = bits;
+            if (bits > 0 && bits < usable) { usable = bits; masked = true; }
         } else {
             (void)hipGetLastError();
         }
         const long cap = (long)occ * usable;
         kspin = cap >= G ? 16 : (int)(cap - 1 < 16 ? cap - 1 : 16);
+        // A masked stream: the launch's CUs are not one pool.  Workgroups are dealt to the 8 XCDs in turn and stay there, so a
+        // waiter on an XCD that the mask left one CU starves that XCD's remaining workgroups however many CUs the others have
+        // free (found with tools/cu_mask_check.py: 8 CUs, one per XCD, 7 waiters -- the kernel never ended).  K = 1 never waits.
+        if (masked) kspin = 1;
         if (kspin < 1) kspin = 1;
     }
     hipLaunchKernelGGL(kf, dim3(G), dim3(1024), lds, s, Y, n, row0, rows, partial, 2, (u32 *)nullptr, rowflag, gate, epoch, out, Gsum, listbuf,
