@@ -1182,7 +1182,10 @@ __global__ __launch_bounds__(A3_NT) SD_A3_ATTR void bucket_rank32_kernel(const d
     const unsigned short *H16 = reinterpret_cast<const unsigned short *>(H);
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int w = blockIdx.x;
+    // the groups of 8 rows NEWEST first: the partition wrote the last rows' records last, and those are the ones the 256 MB
+    // Infinity Cache still holds when this kernel starts (- 1 % at every size measured; blockIdx order: 0.2667 / 0.9026 ms at
+    // 10^5 x 256 / x 1 000, this order 0.2631 / 0.8949)
+    const int w = (int)(((gridDim.x >> 3) / NBT - 1 - (blockIdx.x >> 3) / NBT) * NBT + (blockIdx.x >> 3) % NBT) * 8 + (int)(blockIdx.x & 7);
 #ifdef SD_A3_STAGGER
     // Two workgroups share a CU and would run their load / LDS / store phases in lock-step (the phase times of the kernel add
     // up: profiles/r03e_phase_times_config3.txt).  The workgroups of the second dispatch round start half an item late;
